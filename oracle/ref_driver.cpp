@@ -1,0 +1,255 @@
+// oracle/ref_driver.cpp — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Harness around the UNMODIFIED reference sources where they lie under
+// /root/reference/src (never copied into this repo).  It is compiled by
+// oracle/Makefile into oracle/_ref/ref_render together with the reference's
+// own scene.cpp; the reference's shade() / bp::* / utils.h / parseScene()
+// are therefore the real thing.  Only this container can build it (the GPU
+// box has no /root/reference); its outputs are committed as fixtures under
+// tests/golden/ by tools/make_golden.py.
+//
+// Why a driver instead of the reference's main.cpp: main.cpp:8-9 includes
+// <SDL.h>/<SDL_opengl.h>, SDL2 is not installed in this image, and writing a
+// stand-in SDL header is not allowed.  main.cpp is therefore unbuildable
+// here; the part of it that is on the hot path — the per-pixel loop body
+// main.cpp:129-182 (== :36-85) and the PPM writer main.cpp:199-211 — is
+// restated below and pinned by the reference's one pixel-exact fixture
+// (renders/testcpu.ppm, see tests/test_oracle_golden.py).  Everything the
+// loop calls is reference code.
+//
+// Pinned semantics that differ from "run main.cpp as shipped" (SURVEY.md §0):
+//  * scene.spherical_fog is cleared after parseScene(): scene.cpp:207-212
+//    fills it from uninitialised stack floats (sscanf "fog ..." matches no
+//    field), i.e. undefined behaviour.  "fog line ignored" is the only
+//    reproducible meaning.
+//  * use_shadows is taken from --shadow (main.cpp:244 leaves it
+//    uninitialised when the flag is absent; here absent == false).
+//  * srand(seed) with an explicit --seed instead of srand(time(0))
+//    (main.cpp:400); the loop is serial whenever rand() is consumed so the
+//    draw order is the reference's DFS order.
+//  * --parallel-entry reproduces generate_rays_parallel's overrides
+//    (main.cpp:21-24: 640x480, depth 1, no jitter).
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstdint>
+#include <string>
+#include <unistd.h>
+#include <fcntl.h>
+
+#include "raytrace.h" // the reference's integrator (pulls blinn_phong.h, utils.h, scene.h, glm)
+
+static void write_ppm(const char *path, int w, int h, glm::vec3 *img)
+{
+	// main.cpp:199-211: "P6\nW H\n255\n", then per channel
+	// (unsigned char)(std::min(float(1), c) * 255), row-major, top row first.
+	FILE *f = fopen(path, "wb");
+	if(!f)
+	{
+		fprintf(stderr, "ref_render: cannot write %s\n", path);
+		exit(2);
+	}
+	fprintf(f, "P6\n%d %d\n255\n", w, h);
+	for(int i = 0; i < w * h; i++)
+	{
+		unsigned char px[3] = {(unsigned char) (std::min(float(1), img[i].x) * 255),
+							   (unsigned char) (std::min(float(1), img[i].y) * 255),
+							   (unsigned char) (std::min(float(1), img[i].z) * 255)};
+		fwrite(px, 1, 3, f);
+	}
+	fclose(f);
+}
+
+static void hexf(FILE *f, float v)
+{
+	uint32_t u;
+	memcpy(&u, &v, 4);
+	fprintf(f, " %08x", u);
+}
+static void hex3(FILE *f, glm::vec3 v)
+{
+	hexf(f, v.x);
+	hexf(f, v.y);
+	hexf(f, v.z);
+}
+
+// Dump what parseScene() produced as hex floats, so the product loader and the
+// oracle's loader can be compared with the real one field by field.
+static void dump_scene(const char *path, const Scene &s)
+{
+	FILE *f = fopen(path, "w");
+	fprintf(f, "camera");
+	hex3(f, s.camera.position);
+	hex3(f, s.camera.direction);
+	hex3(f, s.camera.up);
+	hex3(f, s.camera.right);
+	fprintf(f, "\nbackground");
+	hex3(f, s.background);
+	fprintf(f, "\nambient");
+	hex3(f, s.ambient_light.colour);
+	fprintf(f, "\ncounts %zu %zu %zu %zu\n", s.spheres.size(), s.triangles.size(), s.point_lights.size(), s.directional_lights.size());
+	for(size_t i = 0; i < s.spheres.size(); i++)
+	{
+		fprintf(f, "sphere");
+		hex3(f, s.spheres[i].collider.position);
+		hexf(f, s.spheres[i].collider.radius);
+		hex3(f, s.spheres[i].material.ambient);
+		hex3(f, s.spheres[i].material.diffuse);
+		hex3(f, s.spheres[i].material.specular);
+		hexf(f, s.spheres[i].material.power);
+		fprintf(f, "\n");
+	}
+	for(size_t i = 0; i < s.point_lights.size(); i++)
+	{
+		fprintf(f, "point_light");
+		hex3(f, s.point_lights[i].position);
+		hex3(f, s.point_lights[i].colour);
+		fprintf(f, "\n");
+	}
+	for(size_t i = 0; i < s.triangles.size(); i++)
+	{
+		fprintf(f, "triangle");
+		hex3(f, s.triangles[i].v0);
+		hex3(f, s.triangles[i].v1);
+		hex3(f, s.triangles[i].v2);
+		fprintf(f, "\n");
+	}
+	fclose(f);
+}
+
+int main(int argc, char **argv)
+{
+	Options option;
+	const char *path = nullptr, *output = nullptr, *float_out = nullptr, *dump = nullptr;
+	int width = 1920, height = 1080; // scene.h:15 defaults, overridden by CLI (main.cpp:393-395)
+	bool use_shadows = false, parallel_entry = false;
+	unsigned seed = 1;
+
+	for(int i = 1; i < argc; i++)
+	{
+		auto next = [&]() -> const char * { return (i + 1 < argc) ? argv[i + 1] : "0"; };
+		if(!strcmp(argv[i], "--gillum"))
+		{
+			option.monte_carlo	   = true; // main.cpp:252-253
+			option.num_path_traces = atoi(next());
+		}
+		else if(!strcmp(argv[i], "--fov")) option.fov = atof(next());
+		else if(!strcmp(argv[i], "--jsample")) option.grid_size = atoi(next());
+		else if(!strcmp(argv[i], "--width")) width = atoi(next());
+		else if(!strcmp(argv[i], "--height")) height = atoi(next());
+		else if(!strcmp(argv[i], "--depth")) option.max_depth = atoi(next());
+		else if(!strcmp(argv[i], "--shadow")) use_shadows = true;
+		else if(!strcmp(argv[i], "--path")) path = next();
+		else if(!strcmp(argv[i], "--output")) output = next();
+		else if(!strcmp(argv[i], "--seed")) seed = (unsigned) strtoul(next(), nullptr, 10);
+		else if(!strcmp(argv[i], "--float-out")) float_out = next();
+		else if(!strcmp(argv[i], "--dump-scene")) dump = next();
+		else if(!strcmp(argv[i], "--parallel-entry")) parallel_entry = true;
+	}
+	if(!path || (!output && !dump))
+	{
+		fprintf(stderr, "usage: ref_render --path X.scn --output Y.ppm [--width --height --fov --gillum --jsample --depth --shadow --seed --float-out F --dump-scene D --parallel-entry]\n");
+		return 2;
+	}
+
+	// parseScene() echoes every line to stdout and drops simplesphere.txt into
+	// the CWD (scene.cpp:96-102): silence the former, send the latter to /tmp.
+	char resolved[4096];
+	if(!realpath(path, resolved))
+	{
+		fprintf(stderr, "ref_render: no such scene %s\n", path);
+		return 2;
+	}
+	std::string out_abs, fout_abs, dump_abs;
+	char cwd[4096];
+	if(!getcwd(cwd, sizeof cwd)) return 2;
+	auto absol = [&](const char *p) { return (!p) ? std::string() : (p[0] == '/' ? std::string(p) : std::string(cwd) + "/" + p); };
+	out_abs	 = absol(output);
+	fout_abs = absol(float_out);
+	dump_abs = absol(dump);
+	if(chdir("/tmp") != 0) return 2;
+	fflush(stdout);
+	int saved = dup(1);
+	int devnull = open("/dev/null", O_WRONLY);
+	dup2(devnull, 1);
+	Scene scene = parseScene(resolved);
+	fflush(stdout);
+	dup2(saved, 1);
+	close(devnull);
+	close(saved);
+
+	scene.spherical_fog.clear(); // pinned: UB fog line ignored (see header)
+	scene.width		  = width;
+	scene.height	  = height;
+	scene.use_shadows = use_shadows;
+	if(parallel_entry)
+	{ // main.cpp:21-24
+		scene.width		 = 640;
+		scene.height	 = 480;
+		option.max_depth = 1;
+		option.grid_size = 0;
+	}
+	if(dump) dump_scene(dump_abs.c_str(), scene);
+	if(!output) return 0;
+
+	srand(seed);
+	const int W = scene.width, H = scene.height;
+	glm::vec3 *image = new glm::vec3[(size_t) W * H]; // zero-initialised by glm 0.9.5.4's default ctor
+
+	// rand() is consumed iff jitter or GI is on; then the loop must be serial
+	// (DFS draw order).  Otherwise rows are independent and may run in parallel.
+	const bool uses_rand = option.grid_size > 0 || option.monte_carlo;
+#pragma omp parallel for schedule(dynamic, 1) if(!uses_rand)
+	for(int y = 0; y < H; y++)
+	{
+		for(int x = 0; x < W; x++)
+		{
+			// main.cpp:134-137
+			float inv_width	   = 1 / float(scene.width);
+			float inv_height   = 1 / float(scene.height);
+			float aspect_ratio = scene.width / float(scene.height);
+			float angle		   = tan(M_PI * 0.5 * option.fov / 180.);
+			glm::vec3 &px	   = image[(size_t) y * W + x];
+
+			if(option.grid_size > 0)
+			{ // main.cpp:140-166
+				for(int i = 0; i < option.grid_size; i++)
+				{
+					for(int j = 0; j < option.grid_size; j++)
+					{
+						float r = static_cast<float>(rand()) / static_cast<float>(RAND_MAX);
+						float u = (2 * ((x + r) * inv_width) - 1) * angle * aspect_ratio;
+						float v = (1 - 2 * ((y + r) * inv_height)) * angle;
+						glm::vec3 ray_dir(scene.camera.direction + u * scene.camera.right + v * scene.camera.up);
+						Ray ray;
+						ray.position  = scene.camera.position;
+						ray.direction = ray_dir; // main.cpp:155 discards the normalize() result
+						px += shade(ray, scene, option.max_depth, option.monte_carlo, option.num_path_traces);
+					}
+				}
+				px /= (option.grid_size * option.grid_size);
+			}
+			else
+			{ // main.cpp:168-182
+				float u = (2 * ((x + 0.5) * inv_width) - 1) * angle * aspect_ratio;
+				float v = (1 - 2 * ((y + 0.5) * inv_height)) * angle;
+				glm::vec3 ray_dir(scene.camera.direction + u * scene.camera.right + v * scene.camera.up);
+				Ray ray;
+				ray.position  = scene.camera.position;
+				ray.direction = ray_dir;
+				px			  = shade(ray, scene, option.max_depth, option.monte_carlo, option.num_path_traces);
+			}
+		}
+	}
+
+	write_ppm(out_abs.c_str(), W, H, image);
+	if(float_out)
+	{
+		FILE *f = fopen(fout_abs.c_str(), "wb");
+		fwrite(image, sizeof(glm::vec3), (size_t) W * H, f);
+		fclose(f);
+	}
+	delete[] image;
+	return 0;
+}

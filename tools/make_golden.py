@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ from the reference itself (this container only).
+
+Runs oracle/_ref/ref_render — the reference's own shade()/bp::*/parseScene()
+compiled unmodified from /root/reference/src by oracle/Makefile — on the
+reference's scene files and commits the OUTPUTS (PPMs, parsed-scene dumps) as
+fixtures, with the exact command line and seed of each in manifest.json.
+Also copies the data inputs the tests need on the GPU box, where
+/root/reference does not exist: the .scn scene files (data, not source) and the
+reference's one pixel-exact fixture renders/testcpu.ppm.
+
+Usage: python tools/make_golden.py        (needs /root/reference and gcc/g++)
+"""
+import gzip
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+BIN = os.path.join(ROOT, "oracle", "_ref", "ref_render")
+
+# name, scene, args (exactly what ref_render gets, besides --path/--output)
+CASES = [
+    # must equal the reference's own renders/testcpu.ppm
+    ("dragon_parallel_entry", "dragon.scn", ["--parallel-entry"]),
+    # G2/G3 (depth-1 plumbing, with and without shadows)
+    ("spheres1_d1_noshadow", "spheres1.scn", ["--width", "160", "--height", "120", "--depth", "1"]),
+    ("spheres1_d1_shadow", "spheres1.scn", ["--width", "160", "--height", "120", "--depth", "1", "--shadow"]),
+    ("spheres2_shadow", "spheres2.scn", ["--width", "320", "--height", "180", "--shadow"]),
+    ("spheres2_noshadow_fov90", "spheres2.scn", ["--width", "200", "--height", "150", "--fov", "90"]),
+    # G4 = BASELINE config 1 at its real size
+    ("spheres1_640x360_d1", "spheres1.scn", ["--width", "640", "--height", "360", "--depth", "1"]),
+    # G5-G7: rand()-consuming paths, serial, seed pinned
+    ("spheres2_gi16_shadow", "spheres2.scn", ["--width", "160", "--height", "90", "--shadow", "--gillum", "16", "--seed", "20261004"]),
+    ("spheres2_js3_shadow", "spheres2.scn", ["--width", "160", "--height", "90", "--shadow", "--jsample", "3", "--seed", "7"]),
+    ("spheres2_gi4_js2_d2", "spheres2.scn", ["--width", "160", "--height", "90", "--shadow", "--gillum", "4", "--jsample", "2", "--depth", "2", "--seed", "5"]),
+    ("spheres1_gi8_noshadow", "spheres1.scn", ["--width", "160", "--height", "90", "--gillum", "8", "--seed", "99"]),
+    ("spheres2_gi3_d4", "spheres2.scn", ["--width", "96", "--height", "54", "--shadow", "--gillum", "3", "--depth", "4", "--seed", "12"]),
+    # G8: mixed spheres + triangles + unknown commands; many spheres
+    ("test_shadow", "test.scn", ["--width", "160", "--height", "120", "--shadow"]),
+    ("test_gi4", "test.scn", ["--width", "80", "--height", "60", "--shadow", "--gillum", "4", "--seed", "3"]),
+    ("bear_shadow", "bear.scn", ["--width", "160", "--height", "120", "--shadow"]),
+    ("dragon_160x120", "dragon.scn", ["--width", "160", "--height", "120", "--depth", "1"]),
+]
+
+
+def sha(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+def gz_write(src, dst):
+    with open(src, "rb") as f, gzip.GzipFile(dst, "wb", mtime=0) as g:
+        g.write(f.read())
+
+
+def main():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/ref_render"])
+    os.makedirs(os.path.join(GOLD, "scenes"), exist_ok=True)
+    manifest = {"generator": "tools/make_golden.py", "binary": "oracle/_ref/ref_render (reference shade()/parseScene() unmodified)",
+                "cases": {}, "scene_dumps": {}, "reference_fixture": {}}
+    # data inputs
+    for scn in sorted(os.listdir(os.path.join(REF, "scenes"))):
+        if scn.endswith(".scn"):
+            shutil.copyfile(os.path.join(REF, "scenes", scn), os.path.join(GOLD, "scenes", scn))
+            os.chmod(os.path.join(GOLD, "scenes", scn), 0o644)
+    # the reference's own pixel-exact fixture
+    gz_write(os.path.join(REF, "renders", "testcpu.ppm"), os.path.join(GOLD, "testcpu.ppm.gz"))
+    manifest["reference_fixture"]["testcpu.ppm.gz"] = {
+        "source": "renders/testcpu.ppm", "sha256_uncompressed": sha(os.path.join(REF, "renders", "testcpu.ppm")),
+        "meaning": "HEAD `--path scenes/dragon.scn --parallel true` (640x480, depth 1)"}
+    tmp = "/tmp/golden_tmp.ppm"
+    for name, scn, args in CASES:
+        cmd = [BIN, "--path", os.path.join(REF, "scenes", scn), "--output", tmp] + args
+        print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        dst = os.path.join(GOLD, "ref_%s.ppm.gz" % name)
+        gz_write(tmp, dst)
+        manifest["cases"][name] = {"scene": scn, "args": args, "sha256_uncompressed": sha(tmp), "file": os.path.basename(dst)}
+    # parsed-scene dumps of the real parseScene(), hex floats
+    for scn in ["spheres1.scn", "spheres2.scn", "bear.scn", "test.scn", "dragon.scn"]:
+        d = "/tmp/golden_dump.txt"
+        subprocess.check_call([BIN, "--path", os.path.join(REF, "scenes", scn), "--dump-scene", d])
+        dst = os.path.join(GOLD, "scene_dump_%s.txt.gz" % scn[:-4])
+        gz_write(d, dst)
+        manifest["scene_dumps"][scn] = {"file": os.path.basename(dst), "sha256_uncompressed": sha(d)}
+    with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print("wrote", GOLD)
+
+
+if __name__ == "__main__":
+    main()
