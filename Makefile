@@ -1,0 +1,41 @@
+# Top-level build: everything is compiled in-tree for gfx950 (MI355X) only.
+#   skele_raytracer_amd/lib/libskr.so   C-ABI library (include/skr.h): HIP kernels + host loader/writer
+#   bin/raytracer                       the drop-in CLI (reference src/main.cpp:230-413)
+#   oracle/liboracle.so, oracle/_ref/   the checkers (test infrastructure; see oracle/Makefile)
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+CSRC    := skele_raytracer_amd/csrc
+LIBDIR  := skele_raytracer_amd/lib
+# -ffp-contract=off: the arithmetic spec forbids implicit FMA contraction;
+# float divide/sqrt stay correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+            -fno-fast-math -Wall -Wno-unused-function -Iinclude
+KERNEL_SRCS := $(CSRC)/render_kernel.hip
+HOST_SRCS   := $(CSRC)/api.cpp $(CSRC)/scene_host.cpp
+HDRS        := include/skr.h $(CSRC)/device_math.h $(CSRC)/render_params.h $(CSRC)/scene_host.h
+
+all: lib cli oracle
+
+lib: $(LIBDIR)/libskr.so
+cli: bin/raytracer
+
+$(LIBDIR)/libskr.so: $(KERNEL_SRCS) $(HOST_SRCS) $(HDRS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(KERNEL_SRCS) -x hip $(HOST_SRCS)
+
+bin/raytracer: $(CSRC)/raytracer_main.cpp include/skr.h $(LIBDIR)/libskr.so
+	@mkdir -p bin
+	g++ -O2 -std=c++17 -Wall -Iinclude -o $@ $(CSRC)/raytracer_main.cpp -L$(LIBDIR) -lskr -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+
+oracle:
+	$(MAKE) -C oracle all
+
+asm: $(KERNEL_SRCS) $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S -o build/render_kernel.s $(KERNEL_SRCS) -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt
+
+clean:
+	rm -rf $(LIBDIR) bin build
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib cli oracle asm clean

@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline benchmark on MI355X.
+
+Metric (BASELINE.json): Mrays/sec + frame ms, scenes/spheres2.scn 1920x1080 --gillum 16
+--shadow (depth 3), on 1/2/4/8 MI355X.  A "step" is one whole frame: every rank renders its
+interleaved row tiles with the HIP megakernel (C ABI, include/skr.h), the u8 tiles are gathered
+to rank 0 over RCCL and de-interleaved there.  Inputs (the SoA scene) are resident in HBM
+before the timed region.  `value` = radiance rays actually traced per second, whole job
+(rays = shade() calls with depth > 0, counted by the kernel itself; deterministic and
+partition-independent).  SURVEY.md §8d's closed form W*H*S*sum N^k is the full-tree upper
+bound (every ray hitting a sphere) and is reported beside it as `nominal_rays`.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SCENE = os.path.join(ROOT, "tests", "golden", "scenes", "spheres2.scn")
+W, H = 1920, 1080
+KW = dict(gillum=16, shadow=True, depth=3, seed=20261004)
+TILE_ROWS = 8  # interleaved row tiles (cost is very non-uniform vertically: sky rows vs ground rows)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def cpu_baseline(nominal_per_pixel):
+    """The oracle (CPU restatement, counter RNG, OpenMP over rows) timed on this box's host cores
+    on a bounded, representative sample of the same frame: every 8th 8-row tile."""
+    from oracle import pyoracle as orc
+    cores = len(os.sched_getaffinity(0))
+    scene = orc.OracleScene(SCENE)
+    rays = 0
+    t0 = time.perf_counter()
+    rows = 0
+    for t in range(0, (H + TILE_ROWS - 1) // TILE_ROWS, 8):
+        y0, y1 = t * TILE_ROWS, min(H, (t + 1) * TILE_ROWS)
+        _, _, st = orc.render(scene, W, H, rng=orc.RNG_COUNTER, math=orc.MATH_SHARED, y0=y0, y1=y1, threads=cores,
+                              gillum=KW["gillum"], shadow=KW["shadow"], depth=KW["depth"], seed=KW["seed"])
+        rays += int(st[0])
+        rows += y1 - y0
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "oracle/liboracle.so (OpenMP, %d threads), rows of every 8th %d-row tile of the same frame: %d rows, %d radiance rays in %.2f s"
+                      % (cores, TILE_ROWS, rows, rays, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import skele_raytracer_amd as skr
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    scene = skr.parse_scene(SCENE)
+    r = skr.Renderer(scene, local_rank)
+    opt = skr.Options(W, H, **KW)
+    n_tiles_total = (H + TILE_ROWS - 1) // TILE_ROWS
+    k_max = (n_tiles_total + world - 1) // world            # equal-size (padded) tile buffers on every rank
+    mine = torch.zeros((k_max * TILE_ROWS, W, 3), dtype=torch.uint8, device=dev)
+    gathered = [torch.zeros_like(mine) for _ in range(world)] if (world > 1 and rank == 0) else None
+    frame = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
+    stream = torch.cuda.current_stream(dev)
+
+    def step(ev=None):
+        if ev:
+            ev[0].record(stream)
+        r.render_tiles_into(opt, TILE_ROWS, rank, world, mine.data_ptr(), None, stream.cuda_stream)
+        if ev:
+            ev[1].record(stream)
+        if world > 1:
+            dist.gather(mine, gathered, dst=0)
+            if rank == 0:  # de-interleave: tile t lives at rank t % G, slot t // G
+                g = torch.stack(gathered).view(world, k_max, TILE_ROWS, W, 3).permute(1, 0, 2, 3, 4).reshape(-1, W, 3)
+                frame.copy_(g[:H])
+        else:
+            frame.copy_(mine[:H])
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    r.counters(reset=True)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(events[i])
+    sync()
+    dt = time.perf_counter() - t0
+
+    cnt = r.counters(reset=True)
+    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
+    stats = torch.tensor([dt, float(cnt["radiance_rays"]), float(cnt["shadow_rays"]), float(cnt["sphere_hits"]), kernel_ms],
+                         dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt, kernel_ms = float(mx[0]), float(mx[4])
+        rays, shadow, hits = float(sm[1]), float(sm[2]), float(sm[3])
+    else:
+        rays, shadow, hits = float(stats[1]), float(stats[2]), float(stats[3])
+
+    if rank == 0:
+        rays_per_frame = rays / args.steps
+        info = scene.info
+        # algorithmic HBM bytes of one launch of the dominant kernel on this rank: its share of the
+        # u8 framebuffer + one read of the scene ((W*H*3 + scene bytes) per frame)
+        scene_bytes = info.n_spheres * 64 + info.n_point_lights * 32 + info.n_triangles * 48
+        launch_bytes = W * min(H, k_max * TILE_ROWS) * 3 + scene_bytes
+        achieved_gbs = launch_bytes / (kernel_ms * 1e-3) / 1e9
+        # algorithmic flops: 34 flop per ray-sphere test; per radiance ray n_sph tests,
+        # per shadow ray at most n_sph (early-out ignored => upper bound), ~150 flop shading per hit
+        alg_flop = (rays_per_frame * info.n_spheres + shadow / args.steps * info.n_spheres) * 34 + hits / args.steps * 150
+        out = {
+            "metric": "Mrays/sec + frame ms, 1920x1080 gillum=16 spheres2.scn",
+            "value": rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "reference scene file scenes/spheres2.scn (spherical_fog line skipped: UB in the reference)",
+            "config": {"workload": "scenes/spheres2.scn 1920x1080 --gillum 16 --shadow --depth 3 (BASELINE.json configs[2])",
+                       "rays_per_frame": rays_per_frame, "nominal_rays": skr.radiance_ray_count(opt),
+                       "nominal_mrays_per_s": skr.radiance_ray_count(opt) * args.steps / dt / 1e6,
+                       "shadow_rays_per_frame": shadow / args.steps, "partition": "interleaved %d-row tiles, rank = tile %% %d" % (TILE_ROWS, world),
+                       "gather": "RCCL gather of u8 tiles to rank 0" if world > 1 else "none (1 GPU)",
+                       "kernel": r.kernel_variant(), "seed": KW["seed"]},
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "skr_render_kernel<3>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": launch_bytes,
+                         "note": "compulsory HBM traffic is the u8 framebuffer + ~1 KB of scene: this path is FP32-VALU bound, see roofline_valu"},
+            "roofline_valu": {"bound": "fp32_valu", "achieved": alg_flop / (kernel_ms * 1e-3) / 1e12 / world * 1.0,
+                              "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": alg_flop / (kernel_ms * 1e-3) / 1e12 / world / VALU_PEAK_TFLOPS,
+                              "note": "algorithmic flops (34/sphere test, 150/shaded hit; shadow early-outs ignored) per GPU / peak FP32 vector"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(None)
+            out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+/* include/skr.h — C ABI of libskr.so, the MI355X-native replacement for the
+ * reference's per-pixel hot path (lilinitsy/skele-raytracer).
+ *
+ * The reference has no plugin/FFI interface: its seam is the in-process call
+ *     glm::vec3 shade(Ray, Scene, int depth, bool monte_carlo, short num_path_traces)
+ *         src/raytrace.h:139, called once per pixel-sample from src/main.cpp:64,83,162,181
+ * fed by   Scene parseScene(std::string)          src/scene.h:31, src/scene.cpp:12
+ * and      struct Options                         src/utils.h:26-34
+ * and drained by the inline P6 writer             src/main.cpp:199-211 (== :88-100).
+ * This header lifts that seam to frame / row-tile granularity: plain pointers
+ * and sizes, no C++ or torch types.  Every entry point names the reference
+ * interface it replaces.  Return value 0 = ok; otherwise an skr_status (the
+ * reference itself has no error returns: it prints and exits with status 0).
+ *
+ * Threading: a renderer is bound to one HIP device; calls on one renderer must
+ * not overlap; different renderers are independent.  All device work is
+ * enqueued on the caller's stream and is asynchronous unless stated.
+ */
+#ifndef SKR_H
+#define SKR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKR_ABI_VERSION 1
+
+typedef enum {
+	SKR_OK = 0,
+	SKR_ERR_IO = 1,            /* cannot open / write a file */
+	SKR_ERR_ARG = 2,           /* bad argument (null, zero size, bad row range ...) */
+	SKR_ERR_HIP = 3,           /* a HIP runtime call failed; see skr_last_error() */
+	SKR_ERR_UNSUPPORTED = 4,   /* configuration outside what the kernels cover (see skr_last_error()) */
+	SKR_ERR_NO_DEVICE = 5      /* no gfx950 device / HIP runtime unusable: there is NO CPU fallback */
+} skr_status;
+
+/* Host-side scene in the SoA layout that is uploaded to HBM.  Opaque. */
+typedef struct skr_scene skr_scene;
+/* Device context: one HIP device, the scene resident in HBM.  Opaque. */
+typedef struct skr_renderer skr_renderer;
+
+/* Mirrors struct Options (utils.h:26-34) plus the locals main() folds into the
+ * scene before rendering (width/height/use_shadows, main.cpp:236-244,393-396).
+ * skr_options_default() fills the reference's defaults. */
+typedef struct {
+	int32_t width;            /* --width,  default 1920 (scene.h:15) */
+	int32_t height;           /* --height, default 1080 */
+	float fov;                /* --fov degrees, default 60 (utils.h:30) */
+	int32_t monte_carlo;      /* --gillum given (utils.h:28) */
+	int32_t num_path_traces;  /* --gillum N, default 1 (utils.h:31, a short) */
+	int32_t grid_size;        /* --jsample g, default 0 = pixel centres (utils.h:32) */
+	int32_t max_depth;        /* --depth d > 0, default 3 (utils.h:33) */
+	int32_t use_shadows;      /* --shadow (main.cpp:375-378); absent == 0 */
+	uint64_t seed;            /* new: key of the counter RNG that replaces srand(time(0)) (main.cpp:400) */
+} skr_options;
+
+typedef struct {
+	int32_t n_spheres, n_triangles, n_point_lights, n_vertices;
+	int32_t n_directional_dropped; /* parsed and never pushed, scene.cpp:139-163 */
+	int32_t n_fog_skipped;         /* spherical_fog lines (UB in the reference, scene.cpp:207-212): warned + skipped */
+	int32_t n_unknown;             /* "WARNING. Do not know command" lines, scene.cpp:214-217 */
+	int32_t n_bad_triangles;       /* triangle lines whose indices fall outside the vertex pool (skipped) */
+	int32_t film_width, film_height; /* film_resolution: parsed, overridden by the CLI (main.cpp:393-395) */
+	int32_t max_depth_parsed;      /* max_depth: parsed, never read (scene.cpp:192-198) */
+	float camera[13];              /* position, direction, up, right (camera.h:30), half_height_angle */
+	float background[3];
+	float ambient[3];
+} skr_scene_info;
+
+/* ---- scene: replaces Scene parseScene(std::string) (scene.cpp:12-227) ---- */
+/* echo != 0 prints the reference's per-line echo to stdout (scene.cpp:50,...). */
+int skr_scene_create_from_scn(const char *path, int echo, skr_scene **out);
+/* Build a scene from arrays (synthetic tests): spheres[n][14] = centre(3) radius
+ * ambient(3) diffuse(3) specular(3) power; triangles[n][9] = v0 v1 v2;
+ * point_lights[n][6] = position colour; camera[9] = position direction up. */
+int skr_scene_create_from_arrays(const float *spheres, int32_t n_spheres, const float *triangles, int32_t n_triangles,
+								 const float *point_lights, int32_t n_point_lights, const float camera[9],
+								 const float background[3], const float ambient[3], skr_scene **out);
+void skr_scene_destroy(skr_scene *scene);
+int skr_scene_get_info(const skr_scene *scene, skr_scene_info *info);
+/* Copy the parsed arrays back out in the skr_scene_create_from_arrays layouts
+ * (any pointer may be NULL).  Used by the loader parity tests. */
+int skr_scene_get_arrays(const skr_scene *scene, float *spheres, float *triangles, float *point_lights);
+
+/* ---- options: replaces Options' in-class defaults (utils.h:28-33) ---- */
+void skr_options_default(skr_options *opt);
+/* R = W*H*max(1,g*g)*sum_{k<depth} N^k: number of shade() calls with depth > 0
+ * (SURVEY.md §8d); the metric's numerator. */
+uint64_t skr_radiance_ray_count(const skr_options *opt);
+
+/* ---- device ---- */
+int skr_device_count(void);
+/* Uploads the SoA scene to HBM of `device`. */
+int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out);
+void skr_renderer_destroy(skr_renderer *r);
+
+/* The hot path: replaces the loop nest main.cpp:125-197 (== :36-85) and every
+ * shade() call under it, for image rows owned by this caller.
+ *
+ * Rows are grouped in row tiles of `tile_rows` rows; this call renders tiles
+ * first_tile, first_tile + tile_stride, ... (the interleaved partition used to
+ * shard a frame over GPUs: rank r of G passes first_tile = r, tile_stride = G).
+ * Output is compact and tile-major: the k-th rendered tile occupies rows
+ * [k*tile_rows, (k+1)*tile_rows) of d_rgb (W*3 bytes per row, quantised exactly
+ * like main.cpp:205: (unsigned char)(std::min(1.0f, c) * 255)); rows of a final
+ * partial tile beyond the image are left untouched.  d_rgbf, if not NULL,
+ * receives the unquantised float3 image in the same layout (tests).
+ * Both are DEVICE pointers.  stream is a hipStream_t (NULL = default stream).
+ * Random numbers are keyed by the global pixel index, so the image does not
+ * depend on the partition. */
+int skr_render_tiles(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t first_tile,
+					 uint32_t tile_stride, uint8_t *d_rgb, float *d_rgbf, void *stream);
+/* Number of tiles / output rows skr_render_tiles will produce for this partition. */
+uint32_t skr_tile_count(const skr_options *opt, uint32_t tile_rows, uint32_t first_tile, uint32_t tile_stride);
+/* Contiguous rows [y0, y1) (one tile of y1-y0 rows starting at y0). */
+int skr_render_rows(skr_renderer *r, const skr_options *opt, uint32_t y0, uint32_t y1, uint8_t *d_rgb, float *d_rgbf,
+					void *stream);
+/* Work counters accumulated by the kernels since the last reset (synchronous):
+ * out[0] radiance rays = shade() calls with depth > 0, out[1] sphere hits shaded,
+ * out[2] shadow rays (one per light per hit; the reference casts each twice). */
+int skr_renderer_read_counters(skr_renderer *r, uint64_t out[3], int reset);
+/* Whole frame into HOST memory (W*H*3 bytes), synchronous; what the CLI uses. */
+int skr_render_frame_host(skr_renderer *r, const skr_options *opt, uint8_t *h_rgb, float *kernel_ms);
+
+/* ---- image file: replaces the inline writer main.cpp:199-211 ---- */
+int skr_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb);
+
+/* ---- diagnostics ---- */
+const char *skr_last_error(void);      /* thread-local text of the last failure */
+const char *skr_kernel_variant(void);  /* name of the kernel the last render launched */
+/* Device-side evaluation of the arithmetic spec for unit tests: op selects
+ * 0 philox(ctr4,key2 -> out4 u32), 1 sincos(phi -> s,c), 2 powf(x,p),
+ * 3 smallest_root(a,b,c), 4 triangle test (o,d,v0,v1,v2 -> hit,t),
+ * 5 quantise(c -> u8 as u32), 6 basis(n -> nt,nb).  in/out are DEVICE pointers
+ * to n records of the op's input/output width in 32-bit words. */
+int skr_debug_eval(int op, const void *d_in, void *d_out, uint32_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKR_H */

@@ -1,0 +1,248 @@
+"""ctypes binding of lib/libskr.so (include/skr.h).  No compute happens here."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# every symbol include/skr.h declares (tests/test_abi.py checks the library exports them)
+EXPORTED_SYMBOLS = [
+    "skr_scene_create_from_scn", "skr_scene_create_from_arrays", "skr_scene_destroy", "skr_scene_get_info",
+    "skr_scene_get_arrays", "skr_options_default", "skr_radiance_ray_count", "skr_device_count",
+    "skr_renderer_create", "skr_renderer_destroy", "skr_render_tiles", "skr_tile_count", "skr_render_rows",
+    "skr_renderer_read_counters", "skr_render_frame_host", "skr_write_ppm", "skr_last_error",
+    "skr_kernel_variant", "skr_debug_eval",
+]
+
+
+class SkrError(RuntimeError):
+    pass
+
+
+class COptions(C.Structure):
+    # struct skr_options == reference struct Options (utils.h:26-34) + width/height/use_shadows
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fov", C.c_float), ("monte_carlo", C.c_int32),
+                ("num_path_traces", C.c_int32), ("grid_size", C.c_int32), ("max_depth", C.c_int32),
+                ("use_shadows", C.c_int32), ("seed", C.c_uint64)]
+
+
+class CSceneInfo(C.Structure):
+    _fields_ = [("n_spheres", C.c_int32), ("n_triangles", C.c_int32), ("n_point_lights", C.c_int32),
+                ("n_vertices", C.c_int32), ("n_directional_dropped", C.c_int32), ("n_fog_skipped", C.c_int32),
+                ("n_unknown", C.c_int32), ("n_bad_triangles", C.c_int32), ("film_width", C.c_int32),
+                ("film_height", C.c_int32), ("max_depth_parsed", C.c_int32), ("camera", C.c_float * 13),
+                ("background", C.c_float * 3), ("ambient", C.c_float * 3)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libskr.so")
+
+
+_lib = None
+
+
+def lib():
+    """Load libskr.so.  Import torch first when torch is in the process, so that the one
+    libamdhip64.so.7 torch ships is the HIP runtime both sides use."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise SkrError("%s is missing: run `make lib` (or __graft_entry__.build()); there is no fallback path" % path)
+    try:
+        import torch  # noqa: F401  (HIP runtime load order, see docstring)
+    except ImportError:
+        pass
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.skr_scene_create_from_scn.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.skr_scene_create_from_arrays.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, C.c_int32, vp, vp, vp, C.POINTER(vp)]
+    L.skr_scene_destroy.argtypes = [vp]
+    L.skr_scene_destroy.restype = None
+    L.skr_scene_get_info.argtypes = [vp, C.POINTER(CSceneInfo)]
+    L.skr_scene_get_arrays.argtypes = [vp, vp, vp, vp]
+    L.skr_options_default.argtypes = [C.POINTER(COptions)]
+    L.skr_options_default.restype = None
+    L.skr_radiance_ray_count.argtypes = [C.POINTER(COptions)]
+    L.skr_radiance_ray_count.restype = C.c_uint64
+    L.skr_device_count.restype = C.c_int
+    L.skr_renderer_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.skr_renderer_destroy.argtypes = [vp]
+    L.skr_renderer_destroy.restype = None
+    L.skr_render_tiles.argtypes = [vp, C.POINTER(COptions), C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.skr_tile_count.argtypes = [C.POINTER(COptions), C.c_uint32, C.c_uint32, C.c_uint32]
+    L.skr_tile_count.restype = C.c_uint32
+    L.skr_render_rows.argtypes = [vp, C.POINTER(COptions), C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.skr_renderer_read_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+    L.skr_render_frame_host.argtypes = [vp, C.POINTER(COptions), vp, C.POINTER(C.c_float)]
+    L.skr_write_ppm.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
+    L.skr_last_error.restype = C.c_char_p
+    L.skr_kernel_variant.restype = C.c_char_p
+    L.skr_debug_eval.argtypes = [C.c_int, vp, vp, C.c_uint32, vp]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise SkrError("%s failed (status %d): %s" % (what, rc, (lib().skr_last_error() or b"").decode()))
+
+
+class Options:
+    """Reference struct Options (utils.h:26-34) with the reference's defaults, plus the
+    width/height/use_shadows main() folds in (main.cpp:393-396) and the RNG seed."""
+
+    def __init__(self, width=1920, height=1080, fov=60.0, gillum=None, jsample=0, depth=3, shadow=False, seed=1):
+        c = COptions()
+        lib().skr_options_default(C.byref(c))
+        c.width, c.height, c.fov = width, height, fov
+        if gillum is not None:  # main.cpp:252-253: --gillum N sets monte_carlo and num_path_traces
+            c.monte_carlo, c.num_path_traces = 1, gillum
+        c.grid_size, c.max_depth, c.use_shadows, c.seed = jsample, depth, int(bool(shadow)), seed
+        self.c = c
+
+    @property
+    def width(self):
+        return self.c.width
+
+    @property
+    def height(self):
+        return self.c.height
+
+
+def radiance_ray_count(opt):
+    return int(lib().skr_radiance_ray_count(C.byref(opt.c)))
+
+
+class Scene:
+    """Host scene (reference struct Scene, scene.h:13-28) in SoA form; see parse_scene()."""
+
+    def __init__(self, handle):
+        self.h = C.c_void_p(handle)
+
+    def close(self):
+        if self.h:
+            lib().skr_scene_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @property
+    def info(self):
+        i = CSceneInfo()
+        _check(lib().skr_scene_get_info(self.h, C.byref(i)), "skr_scene_get_info")
+        return i
+
+    def arrays(self):
+        i = self.info
+        s = np.zeros((i.n_spheres, 14), np.float32)
+        t = np.zeros((i.n_triangles, 9), np.float32)
+        l = np.zeros((i.n_point_lights, 6), np.float32)
+        _check(lib().skr_scene_get_arrays(self.h, s.ctypes.data, t.ctypes.data, l.ctypes.data), "skr_scene_get_arrays")
+        return s, t, l
+
+    @staticmethod
+    def from_arrays(spheres, triangles, point_lights, camera, background=(0, 0, 0), ambient=(0, 0, 0)):
+        s = np.ascontiguousarray(spheres, np.float32).reshape(-1, 14)
+        t = np.ascontiguousarray(triangles, np.float32).reshape(-1, 9)
+        l = np.ascontiguousarray(point_lights, np.float32).reshape(-1, 6)
+        cam = np.ascontiguousarray(camera, np.float32).reshape(9)
+        bg = np.ascontiguousarray(background, np.float32).reshape(3)
+        am = np.ascontiguousarray(ambient, np.float32).reshape(3)
+        h = C.c_void_p()
+        _check(lib().skr_scene_create_from_arrays(s.ctypes.data, len(s), t.ctypes.data, len(t), l.ctypes.data, len(l),
+                                                  cam.ctypes.data, bg.ctypes.data, am.ctypes.data, C.byref(h)),
+               "skr_scene_create_from_arrays")
+        return Scene(h.value)
+
+
+def parse_scene(path, echo=False):
+    """Reference `Scene parseScene(std::string)` (scene.cpp:12)."""
+    h = C.c_void_p()
+    _check(lib().skr_scene_create_from_scn(os.fsencode(path), int(echo), C.byref(h)), "skr_scene_create_from_scn")
+    return Scene(h.value)
+
+
+def write_ppm(path, rgb):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w, _ = rgb.shape
+    _check(lib().skr_write_ppm(os.fsencode(path), w, h, rgb.ctypes.data), "skr_write_ppm")
+
+
+class Renderer:
+    """Device context (scene resident in HBM) + the launches.  Needs a gfx950 GPU."""
+
+    def __init__(self, scene, device=0):
+        self.scene = scene
+        self.device = device
+        h = C.c_void_p()
+        _check(lib().skr_renderer_create(scene.h, device, C.byref(h)), "skr_renderer_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().skr_renderer_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def tile_count(self, opt, tile_rows, first_tile=0, tile_stride=1):
+        return int(lib().skr_tile_count(C.byref(opt.c), tile_rows, first_tile, tile_stride))
+
+    def render_tiles_into(self, opt, tile_rows, first_tile, tile_stride, rgb_ptr, rgbf_ptr=None, stream=None):
+        """Enqueue the megakernel for this partition; pointers are raw device addresses."""
+        _check(lib().skr_render_tiles(self.h, C.byref(opt.c), tile_rows, first_tile, tile_stride, rgb_ptr, rgbf_ptr,
+                                      stream), "skr_render_tiles")
+
+    def render(self, opt, want_float=False, tile_rows=None, first_tile=0, tile_stride=1):
+        """Render (a partition of) the frame into torch tensors on this device.  Returns
+        (rgb uint8 [rows, W, 3], float32 image or None); rows are tile-major compact."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        tile_rows = tile_rows or opt.height
+        n = self.tile_count(opt, tile_rows, first_tile, tile_stride)
+        rows = n * tile_rows
+        rgb = torch.zeros((rows, opt.width, 3), dtype=torch.uint8, device=dev)
+        rgbf = torch.zeros((rows, opt.width, 3), dtype=torch.float32, device=dev) if want_float else None
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            self.render_tiles_into(opt, tile_rows, first_tile, tile_stride, rgb.data_ptr(),
+                                   rgbf.data_ptr() if want_float else None, stream)
+        return rgb, rgbf
+
+    def render_rows(self, opt, y0, y1, want_float=False):
+        import torch
+        dev = torch.device("cuda", self.device)
+        rgb = torch.zeros((y1 - y0, opt.width, 3), dtype=torch.uint8, device=dev)
+        rgbf = torch.zeros((y1 - y0, opt.width, 3), dtype=torch.float32, device=dev) if want_float else None
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _check(lib().skr_render_rows(self.h, C.byref(opt.c), y0, y1, rgb.data_ptr(),
+                                         rgbf.data_ptr() if want_float else None, stream), "skr_render_rows")
+        return rgb, rgbf
+
+    def counters(self, reset=True):
+        out = (C.c_uint64 * 3)()
+        _check(lib().skr_renderer_read_counters(self.h, out, int(reset)), "skr_renderer_read_counters")
+        return {"radiance_rays": int(out[0]), "sphere_hits": int(out[1]), "shadow_rays": int(out[2])}
+
+    @staticmethod
+    def kernel_variant():
+        return (lib().skr_kernel_variant() or b"").decode()
+
+
+def debug_eval(op, inp, out_words_per_record, device=0):
+    """Run the arithmetic-spec debug kernel on n records (uint32 words)."""
+    import torch
+    dev = torch.device("cuda", device)
+    a = torch.from_numpy(np.ascontiguousarray(inp).view(np.uint32).astype(np.int64)).to(torch.int64)
+    a = a.to(dev).to(torch.int32).contiguous()  # same bits as uint32
+    n = a.shape[0]
+    o = torch.zeros((n, out_words_per_record), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().skr_debug_eval(op, a.data_ptr(), o.data_ptr(), n, torch.cuda.current_stream(dev).cuda_stream),
+               "skr_debug_eval")
+    torch.cuda.synchronize(dev)
+    return o.cpu().numpy().view(np.uint32)

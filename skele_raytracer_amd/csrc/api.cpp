@@ -1,0 +1,293 @@
+// C ABI glue: device context, scene upload, launches (include/skr.h).
+// There is deliberately no CPU fallback: without a usable HIP device every
+// device entry point fails with SKR_ERR_NO_DEVICE / SKR_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "render_params.h"
+#include "scene_host.h"
+
+hipError_t skr_launch_render(const RenderParams &p, hipStream_t stream, const char **variant);
+hipError_t skr_launch_debug(int op, const void *d_in, void *d_out, uint32_t n, hipStream_t stream);
+size_t skr_render_lds_bytes(const RenderParams &p);
+
+static thread_local const char *g_variant = "none";
+
+#define SKR_HIP(call)                                                                                      \
+	do                                                                                                     \
+	{                                                                                                      \
+		hipError_t e_ = (call);                                                                            \
+		if(e_ != hipSuccess)                                                                               \
+		{                                                                                                  \
+			skr_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);     \
+			return SKR_ERR_HIP;                                                                            \
+		}                                                                                                  \
+	} while(0)
+
+struct skr_renderer {
+	int device = 0;
+	skr_scene_info info{};
+	float4 *d_blob = nullptr; // one allocation: geom | amb | kd | ks | lights | tris
+	size_t off_amb = 0, off_kd = 0, off_ks = 0, off_lights = 0, off_tris = 0;
+	unsigned long long *d_counters = nullptr;
+	int lds_limit = 0;
+};
+
+extern "C" {
+
+int skr_device_count(void)
+{
+	int n = 0;
+	if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
+{
+	if(!scene || !out)
+	{
+		skr_set_error("skr_renderer_create: null argument");
+		return SKR_ERR_ARG;
+	}
+	*out = nullptr;
+	int n = 0;
+	if(hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+	{
+		skr_set_error("no usable HIP device (count=%d, asked for %d); libskr has no CPU fallback", n, device);
+		return SKR_ERR_NO_DEVICE;
+	}
+	SKR_HIP(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	SKR_HIP(hipGetDeviceProperties(&prop, device));
+	if(strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+	{
+		skr_set_error("device %d is %s; libskr is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+		return SKR_ERR_NO_DEVICE;
+	}
+	skr_renderer *r = new skr_renderer();
+	r->device = device;
+	r->info = scene->info;
+	r->lds_limit = (int) prop.sharedMemPerBlock;
+	const size_t ns = scene->sph_geom.size(), nl2 = scene->lights.size(), nt3 = scene->tris.size();
+	r->off_amb = ns;
+	r->off_kd = 2 * ns;
+	r->off_ks = 3 * ns;
+	r->off_lights = 4 * ns;
+	r->off_tris = 4 * ns + nl2;
+	const size_t total = 4 * ns + nl2 + nt3;
+	std::vector<skr_f4> blob(total > 0 ? total : 1);
+	if(ns)
+	{
+		memcpy(&blob[0], scene->sph_geom.data(), ns * 16);
+		memcpy(&blob[r->off_amb], scene->sph_amb.data(), ns * 16);
+		memcpy(&blob[r->off_kd], scene->sph_kd.data(), ns * 16);
+		memcpy(&blob[r->off_ks], scene->sph_ks.data(), ns * 16);
+	}
+	if(nl2) memcpy(&blob[r->off_lights], scene->lights.data(), nl2 * 16);
+	if(nt3) memcpy(&blob[r->off_tris], scene->tris.data(), nt3 * 16);
+	hipError_t e = hipMalloc((void **) &r->d_blob, blob.size() * 16);
+	if(e == hipSuccess) e = hipMemcpy(r->d_blob, blob.data(), blob.size() * 16, hipMemcpyHostToDevice);
+	if(e == hipSuccess) e = hipMalloc((void **) &r->d_counters, 8 * sizeof(unsigned long long));
+	if(e == hipSuccess) e = hipMemset(r->d_counters, 0, 8 * sizeof(unsigned long long));
+	if(e != hipSuccess)
+	{
+		skr_set_error("scene upload failed: %s", hipGetErrorString(e));
+		if(r->d_blob) (void) hipFree(r->d_blob);
+		if(r->d_counters) (void) hipFree(r->d_counters);
+		delete r;
+		return SKR_ERR_HIP;
+	}
+	*out = r;
+	return SKR_OK;
+}
+
+void skr_renderer_destroy(skr_renderer *r)
+{
+	if(!r) return;
+	(void) hipSetDevice(r->device);
+	if(r->d_blob) (void) hipFree(r->d_blob);
+	if(r->d_counters) (void) hipFree(r->d_counters);
+	delete r;
+}
+
+uint32_t skr_tile_count(const skr_options *opt, uint32_t tile_rows, uint32_t first_tile, uint32_t tile_stride)
+{
+	if(!opt || opt->height <= 0 || tile_rows == 0 || tile_stride == 0) return 0;
+	const uint32_t total = ((uint32_t) opt->height + tile_rows - 1) / tile_rows;
+	if(first_tile >= total) return 0;
+	return (total - first_tile + tile_stride - 1) / tile_stride;
+}
+
+static int check_options(const skr_options *opt)
+{
+	if(opt->width <= 0 || opt->height <= 0 || opt->width > 65536 || opt->height > 65536)
+	{
+		skr_set_error("bad image size %dx%d", opt->width, opt->height);
+		return SKR_ERR_ARG;
+	}
+	if(opt->max_depth <= 0)
+	{ // main.cpp:318-329: "depth takes a positive int"
+		skr_set_error("depth takes a positive int after flag for the max depth");
+		return SKR_ERR_ARG;
+	}
+	if(opt->max_depth > 6)
+	{
+		skr_set_error("--depth %d: the GPU path instantiates depths 1..6", opt->max_depth);
+		return SKR_ERR_UNSUPPORTED;
+	}
+	if(opt->grid_size < 0 || opt->grid_size > 1024 || opt->num_path_traces < 0 || opt->num_path_traces > 32767)
+	{
+		skr_set_error("jsample/gillum out of range (%d, %d)", opt->grid_size, opt->num_path_traces);
+		return SKR_ERR_ARG;
+	}
+	if(opt->monte_carlo)
+	{ // tree node ids are 32-bit RNG counter words: need N^(depth-1) < 2^32
+		double nodes = 1;
+		for(int k = 1; k < opt->max_depth; k++) nodes = nodes * (double) opt->num_path_traces + 1;
+		if(nodes >= 4294967296.0)
+		{
+			skr_set_error("gillum %d at depth %d needs more than 2^32 tree nodes per sample", opt->num_path_traces, opt->max_depth);
+			return SKR_ERR_UNSUPPORTED;
+		}
+	}
+	return SKR_OK;
+}
+
+static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t first_tile, uint32_t tile_stride,
+					   uint32_t max_tiles, uint8_t *d_rgb, float *d_rgbf, void *stream)
+{
+	if(!r || !opt || (!d_rgb && !d_rgbf) || tile_rows == 0 || tile_stride == 0)
+	{
+		skr_set_error("skr_render_tiles: bad argument");
+		return SKR_ERR_ARG;
+	}
+	int rc = check_options(opt);
+	if(rc != SKR_OK) return rc;
+	uint32_t n_tiles = skr_tile_count(opt, tile_rows, first_tile, tile_stride);
+	if(n_tiles > max_tiles) n_tiles = max_tiles;
+	if(n_tiles == 0) return SKR_OK;
+	SKR_HIP(hipSetDevice(r->device));
+
+	RenderParams p{};
+	p.width = opt->width;
+	p.height = opt->height;
+	p.tile_rows = tile_rows;
+	p.first_tile = first_tile;
+	p.tile_stride = tile_stride;
+	p.out_rows = n_tiles * tile_rows;
+	// main.cpp:134-137, hoisted: identical float/double expressions evaluated once
+	p.inv_width = 1 / float(opt->width);
+	p.inv_height = 1 / float(opt->height);
+	p.aspect = opt->width / float(opt->height);
+	p.angle = (float) tan(M_PI * 0.5 * opt->fov / 180.);
+	const float *c = r->info.camera;
+	p.cam_pos = f3{c[0], c[1], c[2]};
+	p.cam_dir = f3{c[3], c[4], c[5]};
+	p.cam_up = f3{c[6], c[7], c[8]};
+	p.cam_right = f3{c[9], c[10], c[11]};
+	p.background = f3{r->info.background[0], r->info.background[1], r->info.background[2]};
+	p.n_spheres = r->info.n_spheres;
+	p.n_tris = r->info.n_triangles;
+	p.n_lights = r->info.n_point_lights;
+	p.sph_geom = r->d_blob;
+	p.sph_amb = r->d_blob + r->off_amb;
+	p.sph_kd = r->d_blob + r->off_kd;
+	p.sph_ks = r->d_blob + r->off_ks;
+	p.lights = r->d_blob + r->off_lights;
+	p.tris = r->d_blob + r->off_tris;
+	p.monte_carlo = opt->monte_carlo ? 1 : 0;
+	p.num_path_traces = opt->num_path_traces;
+	p.grid_size = opt->grid_size;
+	p.max_depth = opt->max_depth;
+	p.use_shadows = opt->use_shadows ? 1 : 0;
+	p.seed_lo = (uint32_t) opt->seed;
+	p.seed_hi = (uint32_t) (opt->seed >> 32);
+	p.rgb = d_rgb;
+	p.rgbf = d_rgbf;
+	p.counters = r->d_counters;
+	if(skr_render_lds_bytes(p) > (size_t) r->lds_limit)
+	{
+		skr_set_error("scene needs %zu bytes of LDS (%d spheres, %d lights); the device allows %d per workgroup", skr_render_lds_bytes(p),
+					  p.n_spheres, p.n_lights, r->lds_limit);
+		return SKR_ERR_UNSUPPORTED;
+	}
+	SKR_HIP(skr_launch_render(p, (hipStream_t) stream, &g_variant));
+	return SKR_OK;
+}
+
+int skr_render_tiles(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t first_tile, uint32_t tile_stride,
+					 uint8_t *d_rgb, float *d_rgbf, void *stream)
+{
+	return render_impl(r, opt, tile_rows, first_tile, tile_stride, 0xffffffffu, d_rgb, d_rgbf, stream);
+}
+
+int skr_render_rows(skr_renderer *r, const skr_options *opt, uint32_t y0, uint32_t y1, uint8_t *d_rgb, float *d_rgbf, void *stream)
+{
+	if(!opt || y1 <= y0 || y1 > (uint32_t) opt->height)
+	{
+		skr_set_error("skr_render_rows: bad row range [%u,%u)", y0, y1);
+		return SKR_ERR_ARG;
+	}
+	// rows [y0,y1) = consecutive tiles of g = gcd(y0, y1-y0) rows starting at tile y0/g
+	uint32_t a = y0, b = y1 - y0;
+	while(b)
+	{
+		const uint32_t t = a % b;
+		a = b;
+		b = t;
+	}
+	return render_impl(r, opt, a, y0 / a, 1, (y1 - y0) / a, d_rgb, d_rgbf, stream);
+}
+
+int skr_renderer_read_counters(skr_renderer *r, uint64_t out[3], int reset)
+{
+	if(!r || !out) return SKR_ERR_ARG;
+	SKR_HIP(hipSetDevice(r->device));
+	unsigned long long h[3];
+	SKR_HIP(hipMemcpy(h, r->d_counters, sizeof h, hipMemcpyDeviceToHost)); // synchronises with prior launches
+	for(int k = 0; k < 3; k++) out[k] = h[k];
+	if(reset) SKR_HIP(hipMemset(r->d_counters, 0, 8 * sizeof(unsigned long long)));
+	return SKR_OK;
+}
+
+int skr_render_frame_host(skr_renderer *r, const skr_options *opt, uint8_t *h_rgb, float *kernel_ms)
+{
+	if(!r || !opt || !h_rgb) return SKR_ERR_ARG;
+	SKR_HIP(hipSetDevice(r->device));
+	const size_t bytes = (size_t) opt->width * opt->height * 3;
+	uint8_t *d = nullptr;
+	SKR_HIP(hipMalloc((void **) &d, bytes));
+	hipEvent_t e0, e1;
+	SKR_HIP(hipEventCreate(&e0));
+	SKR_HIP(hipEventCreate(&e1));
+	SKR_HIP(hipEventRecord(e0, nullptr));
+	int rc = skr_render_tiles(r, opt, (uint32_t) opt->height, 0, 1, d, nullptr, nullptr);
+	if(rc == SKR_OK)
+	{
+		SKR_HIP(hipEventRecord(e1, nullptr));
+		SKR_HIP(hipMemcpy(h_rgb, d, bytes, hipMemcpyDeviceToHost));
+		float ms = 0;
+		SKR_HIP(hipEventElapsedTime(&ms, e0, e1));
+		if(kernel_ms) *kernel_ms = ms;
+	}
+	(void) hipEventDestroy(e0);
+	(void) hipEventDestroy(e1);
+	(void) hipFree(d);
+	return rc;
+}
+
+const char *skr_kernel_variant(void) { return g_variant; }
+
+int skr_debug_eval(int op, const void *d_in, void *d_out, uint32_t n, void *stream)
+{
+	if(!d_in || !d_out || op < 0 || op > 6) return SKR_ERR_ARG;
+	if(n == 0) return SKR_OK;
+	SKR_HIP(skr_launch_debug(op, d_in, d_out, n, (hipStream_t) stream));
+	return SKR_OK;
+}
+
+} // extern "C"

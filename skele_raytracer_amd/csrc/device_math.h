@@ -1,0 +1,214 @@
+// Device-side arithmetic of the hot path (gfx950 only).
+//
+// Every function here has to produce the same BITS as the reference's host
+// arithmetic (IEEE binary32/64, round-to-nearest-even, glm 0.9.5.4 operation
+// order), so the kernels are compiled with -ffp-contract=off and use fma() only
+// where the arithmetic spec (DESIGN.md "Arithmetic spec") writes one.  Float
+// divide and sqrt are the correctly rounded forms (hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt; asserted by tests/test_gpu_units.py).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "render_params.h" // struct f3
+
+#define SKR_DEV static __device__ __forceinline__
+
+SKR_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+SKR_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+SKR_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+SKR_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+SKR_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+SKR_DEV f3 operator/(f3 a, float s) { return mk3(__fdiv_rn(a.x, s), __fdiv_rn(a.y, s), __fdiv_rn(a.z, s)); } // glm: per-component divide
+SKR_DEV f3 add_scalar(f3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
+// glm::dot for vec3: (x + y) + z of the component products (func_geometric.inl:66-73)
+SKR_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// glm::cross operand order (func_geometric.inl:216-226)
+SKR_DEV f3 cross3(f3 x, f3 y) { return mk3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+SKR_DEV float sqr3(f3 v) { return (v.x * v.x + v.y * v.y) + v.z * v.z; }
+SKR_DEV float length3(f3 v) { return __fsqrt_rn(sqr3(v)); }
+// glm::normalize: v * (1.0f / sqrt(sum)) (func_geometric.inl:253-261, func_exponential.inl:226-229)
+SKR_DEV f3 normalize3(f3 v) { return v * __fdiv_rn(1.0f, __fsqrt_rn(sqr3(v))); }
+// std::max(0.0f, x): NaN -> 0
+SKR_DEV float max0(float x) { return (0.0f < x) ? x : 0.0f; }
+SKR_DEV f3 ld3(const float4 v) { return mk3(v.x, v.y, v.z); }
+
+// ---------------------------------------------------------------- RNG ----
+// Philox4x32-10 (Salmon et al., SC'11).  One call yields the (r1, r2) pairs of
+// two sibling GI rays.
+SKR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+	for(int r = 0; r < 10; r++)
+	{
+		const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+		const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+		const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+		c0 = n0;
+		c1 = lo1;
+		c2 = n2;
+		c3 = lo0;
+		k0 += 0x9E3779B9u;
+		k1 += 0xBB67AE85u;
+	}
+	out[0] = c0;
+	out[1] = c1;
+	out[2] = c2;
+	out[3] = c3;
+}
+
+// float(k) / float(RAND_MAX) with k = 31 random bits: the map the reference
+// applies to rand() (raytrace.h:119-120, main.cpp:146); float(RAND_MAX) == 2^31.
+SKR_DEV float u31_to_unit(uint32_t w) { return (float) (w >> 1) * 4.656612873077392578125e-10f; } // * 2^-31 is exact
+
+// ------------------------------------------------------- shared math ----
+// sin/cos of a binary32 angle evaluated in binary64, rounded once.
+SKR_DEV void sincos_spec(float phi, float &s, float &c)
+{
+	const double x = (double) phi;
+	const double kd = rint(x * 0x1.45F306DC9C883p-1); // 2/pi
+	const int k = (int) kd;
+	double y = fma(-kd, 0x1.921FB544p+0, x);        // pi/2 high 33 bits
+	y = fma(-kd, 0x1.0B4611A626331p-34, y);         // pi/2 low
+	const double z = y * y;
+	double ps = -1.0 / 1307674368000.0;
+	ps = fma(ps, z, 1.0 / 6227020800.0);
+	ps = fma(ps, z, -1.0 / 39916800.0);
+	ps = fma(ps, z, 1.0 / 362880.0);
+	ps = fma(ps, z, -1.0 / 5040.0);
+	ps = fma(ps, z, 1.0 / 120.0);
+	ps = fma(ps, z, -1.0 / 6.0);
+	const double sy = fma(y * z, ps, y);
+	double pc = 1.0 / 20922789888000.0;
+	pc = fma(pc, z, -1.0 / 87178291200.0);
+	pc = fma(pc, z, 1.0 / 479001600.0);
+	pc = fma(pc, z, -1.0 / 3628800.0);
+	pc = fma(pc, z, 1.0 / 40320.0);
+	pc = fma(pc, z, -1.0 / 720.0);
+	pc = fma(pc, z, 1.0 / 24.0);
+	pc = fma(pc, z, -0.5);
+	const double cy = fma(z, pc, 1.0);
+	const int q = k & 3;
+	const double sv = (q == 0) ? sy : (q == 1) ? cy : (q == 2) ? -sy : -cy;
+	const double cv = (q == 0) ? cy : (q == 1) ? -sy : (q == 2) ? -cy : sy;
+	s = (float) sv;
+	c = (float) cv;
+}
+
+// powf(x, p), x >= 0, as 2^(p log2 x) in binary64, rounded once.
+SKR_DEV float powf_spec(float x, float p)
+{
+	if(p == 0.0f) return 1.0f;
+	if(x != x || p != p) return x + p;
+	if(x == 0.0f) return (p > 0.0f) ? 0.0f : __builtin_inff();
+	if(x == 1.0f) return 1.0f;
+	if(x == __builtin_inff()) return (p > 0.0f) ? __builtin_inff() : 0.0f;
+	if(x < 0.0f) return __builtin_nanf("");
+	const uint64_t b = (uint64_t) __double_as_longlong((double) x);
+	int e = (int) ((b >> 52) & 0x7ff) - 1023;
+	double m = __longlong_as_double((long long) ((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull));
+	if(m > 0x1.6A09E667F3BCDp+0)
+	{
+		m *= 0.5;
+		e += 1;
+	}
+	const double s = (m - 1.0) / (m + 1.0);
+	const double s2 = s * s;
+	double q = 1.0 / 21.0;
+	q = fma(q, s2, 1.0 / 19.0);
+	q = fma(q, s2, 1.0 / 17.0);
+	q = fma(q, s2, 1.0 / 15.0);
+	q = fma(q, s2, 1.0 / 13.0);
+	q = fma(q, s2, 1.0 / 11.0);
+	q = fma(q, s2, 1.0 / 9.0);
+	q = fma(q, s2, 1.0 / 7.0);
+	q = fma(q, s2, 1.0 / 5.0);
+	q = fma(q, s2, 1.0 / 3.0);
+	q = fma(q, s2, 1.0);
+	const double ln_m = 2.0 * s * q;
+	const double log2x = fma(ln_m, 0x1.71547652B82FEp+0, (double) e);
+	const double y = (double) p * log2x;
+	if(y >= 128.0) return __builtin_inff();
+	if(y < -150.0) return 0.0f;
+	const double n = rint(y);
+	const double t = (y - n) * 0x1.62E42FEFA39EFp-1;
+	double r = 1.0 / 6227020800.0;
+	r = fma(r, t, 1.0 / 479001600.0);
+	r = fma(r, t, 1.0 / 39916800.0);
+	r = fma(r, t, 1.0 / 3628800.0);
+	r = fma(r, t, 1.0 / 362880.0);
+	r = fma(r, t, 1.0 / 40320.0);
+	r = fma(r, t, 1.0 / 5040.0);
+	r = fma(r, t, 1.0 / 720.0);
+	r = fma(r, t, 1.0 / 120.0);
+	r = fma(r, t, 1.0 / 24.0);
+	r = fma(r, t, 1.0 / 6.0);
+	r = fma(r, t, 0.5);
+	r = fma(r, t, 1.0);
+	r = fma(r, t, 1.0);
+	const double scale = __longlong_as_double((long long) ((uint64_t) ((int) n + 1023) << 52));
+	return (float) (r * scale);
+}
+
+// ---------------------------------------------------------- geometry ----
+// utils.h:87-110 smallest_root given the float discriminant D >= 0.
+// -b and 2a are floats promoted to double; sqrt and the divide are binary64
+// (the unqualified sqrt() binds to ::sqrt(double)); one
+// rounding to float.  Only the near root can be returned.
+SKR_DEV float near_root_exact(float two_a, float b, float D)
+{
+	const double q = ((double) (-b) - sqrt((double) D)) / (double) two_a;
+	const float t2 = (float) q;
+	return (t2 >= 0.0f) ? t2 : __builtin_inff();
+}
+
+// utils.h:87 + :113 for one sphere.  two_a = 2*a, four_a = 4*a are per-ray
+// invariants (exact doublings of a = dot(d,d)).
+SKR_DEV float sphere_distance(f3 o, f3 d, float two_a, float four_a, float4 sph)
+{
+	const f3 e = o - ld3(sph);
+	const float b = 2 * dot3(d, e);
+	const float c = dot3(e, e) - sph.w; // sph.w = radius*radius
+	const float D = b * b - four_a * c;
+	if(D < 0) return __builtin_inff();
+	return near_root_exact(two_a, b, D);
+}
+
+// utils.h:169-179
+SKR_DEV bool accept_distance(float t) { return !(t <= 1.0f || t == __builtin_inff()); }
+
+// utils.h:181-213 with the edges e1 = v1-v0, e2 = v2-v0 precomputed on the host
+// (same subtractions).  u carries the reference's flipped sign; no t>0 test.
+SKR_DEV bool triangle_hit(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float &t)
+{
+	const f3 p = cross3(d, e2);
+	const float det = dot3(e1, p);
+	if(fabsf(det) < 0.00001f) return false;
+	const float inv = __fdiv_rn(1.0f, det);
+	const f3 tv = o - v0;
+	const float u = inv * dot3(mk3(-tv.x, -tv.y, -tv.z), p);
+	if(u < 0 || u > 1) return false;
+	const f3 q = cross3(tv, e1);
+	const float v = dot3(d, q) * inv;
+	if(v < 0 || u + v > 1) return false;
+	t = dot3(e2, q) * inv;
+	return true;
+}
+
+// utils.h:148-165 transform_coordinate_space
+SKR_DEV void tangent_basis(f3 n, f3 &nt, f3 &nb)
+{
+	if(fabsf(n.x) > fabsf(n.y)) nt = mk3(n.z, 0.0f, -n.x) / __fsqrt_rn(n.x * n.x + n.z * n.z);
+	else nt = mk3(0.0f, -n.z, n.y) / __fsqrt_rn(n.y * n.y + n.z * n.z);
+	nb = cross3(n, nt);
+}
+
+// main.cpp:205: (unsigned char)(std::min(float(1), c) * 255); NaN -> 255
+SKR_DEV uint32_t quantise(float c)
+{
+	const float m = (c < 1.0f) ? c : 1.0f;
+	const float s = m * 255;
+	if(!(s > -2147483648.0f)) return 0;
+	return (uint32_t) (int32_t) s & 0xffu;
+}

@@ -1,0 +1,161 @@
+// raytracer — drop-in command line of the reference (src/main.cpp:230-413):
+//   ./raytracer --path scene.scn --output image.ppm [--width i] [--height i] [--fov f]
+//               [--gillum n] [--jsample g] [--depth d] [--parallel true|false] [--shadow]
+// Flags are matched by strcmp anywhere in argv and unknown tokens are ignored,
+// messages and the exit-status-0 convention follow the reference.  New,
+// non-colliding flags: --seed u64 (counter-RNG key; the reference seeds rand()
+// with time(0)), --device i, --quiet (no per-line scene echo).
+// The frame itself is rendered by libskr on the GPU; there is no CPU path here.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <vector>
+
+#include "skr.h"
+
+int main(int argc, char *argv[])
+{
+	skr_options option;
+	skr_options_default(&option);
+	const char *path = nullptr, *output = nullptr;
+	bool visual = true; // utils.h:29; kept for compatibility: there is no SDL viewer, both values render on the GPU
+	bool quiet = false;
+	int device = 0;
+
+	for(int i = 0; i < argc; i++)
+	{
+		const bool has_next = i + 1 < argc;
+		if(!strcmp(argv[i], "--gillum"))
+		{
+			if(has_next)
+			{
+				option.monte_carlo = 1;
+				option.num_path_traces = atoi(argv[i + 1]);
+			}
+			else std::cerr << "gillum takes an int after flag for the number of paths traced" << std::endl; // main.cpp:258: warns, goes on
+		}
+		if(!strcmp(argv[i], "--fov"))
+		{
+			if(!has_next)
+			{
+				std::cerr << "fov takes a float (degrees) after flag for the field of view" << std::endl;
+				return 0;
+			}
+			option.fov = (float) atof(argv[i + 1]);
+		}
+		if(!strcmp(argv[i], "--jsample"))
+		{
+			if(!has_next)
+			{
+				std::cerr << "jsample takes an int after flag for the supersampling grid size" << std::endl;
+				return 0;
+			}
+			option.grid_size = atoi(argv[i + 1]);
+		}
+		if(!strcmp(argv[i], "--width"))
+		{
+			if(!has_next)
+			{
+				std::cerr << "width takes an int after flag for the width" << std::endl;
+				return 0;
+			}
+			option.width = atoi(argv[i + 1]);
+		}
+		if(!strcmp(argv[i], "--height"))
+		{
+			if(!has_next)
+			{
+				std::cerr << "height takes an int after flag for the width" << std::endl;
+				return 0;
+			}
+			option.height = atoi(argv[i + 1]);
+		}
+		if(!strcmp(argv[i], "--depth"))
+		{
+			if(!has_next || atoi(argv[i + 1]) <= 0)
+			{
+				std::cerr << "depth takes a positive int after flag for the max depth" << std::endl;
+				return 0;
+			}
+			option.max_depth = atoi(argv[i + 1]);
+		}
+		if(!strcmp(argv[i], "--parallel"))
+		{
+			if(has_next && !strcmp(argv[i + 1], "true")) visual = false;
+			if(has_next && !strcmp(argv[i + 1], "false")) visual = true;
+		}
+		if(!strcmp(argv[i], "--path"))
+		{
+			if(!has_next)
+			{
+				std::cerr << "path must be passed after --path" << std::endl;
+				return 0;
+			}
+			path = argv[i + 1];
+		}
+		if(!strcmp(argv[i], "--output"))
+		{
+			if(!has_next)
+			{
+				std::cerr << "output path must be passed after --output" << std::endl;
+				return 0;
+			}
+			output = argv[i + 1];
+		}
+		if(!strcmp(argv[i], "--shadow")) option.use_shadows = 1;
+		if(!strcmp(argv[i], "--seed") && has_next) option.seed = strtoull(argv[i + 1], nullptr, 10);
+		if(!strcmp(argv[i], "--device") && has_next) device = atoi(argv[i + 1]);
+		if(!strcmp(argv[i], "--quiet")) quiet = true;
+	}
+	if(!path)
+	{
+		std::cerr << "no scene file was passed. Pass with --path path_to_scn" << std::endl;
+		return 0;
+	}
+	if(!output)
+	{
+		std::cerr << "no output destination was passed. Pass with --output destination_path.ppm" << std::endl;
+		return 0;
+	}
+
+	skr_scene *scene = nullptr;
+	if(skr_scene_create_from_scn(path, quiet ? 0 : 1, &scene) != SKR_OK)
+	{
+		printf("%s\n", skr_last_error()); // scene.cpp:24-25: message, exit(0)
+		return 0;
+	}
+	// utils.h:35-38 Options::to_string
+	printf("\n\nMonte carlo: %d\nvisual display: %d\nfov: %f\nnum paths traced: %d\nsupersample grid size: %d\nmax depth: %d\n",
+		   option.monte_carlo, visual ? 1 : 0, option.fov, option.num_path_traces, option.grid_size, option.max_depth);
+
+	skr_renderer *renderer = nullptr;
+	int rc = skr_renderer_create(scene, device, &renderer);
+	if(rc != SKR_OK)
+	{
+		std::cerr << "raytracer: " << skr_last_error() << std::endl;
+		return rc; // new failure class (the reference has no device): non-zero
+	}
+	std::vector<uint8_t> rgb((size_t) option.width * option.height * 3);
+	float ms = 0;
+	rc = skr_render_frame_host(renderer, &option, rgb.data(), &ms);
+	if(rc != SKR_OK)
+	{
+		std::cerr << "raytracer: " << skr_last_error() << std::endl;
+		return rc;
+	}
+	uint64_t counters[3] = {0, 0, 0};
+	skr_renderer_read_counters(renderer, counters, 0);
+	rc = skr_write_ppm(output, (uint32_t) option.width, (uint32_t) option.height, rgb.data());
+	if(rc != SKR_OK)
+	{
+		std::cerr << "raytracer: " << skr_last_error() << std::endl;
+		return rc;
+	}
+	printf("***\nWROTE TO PPM\n***\n"); // main.cpp:213
+	fprintf(stderr, "{\"kernel\": \"%s\", \"frame_ms\": %.3f, \"radiance_rays\": %llu, \"mrays_per_s\": %.1f, \"shadow_rays\": %llu}\n",
+			skr_kernel_variant(), ms, (unsigned long long) counters[0], ms > 0 ? counters[0] / (ms * 1e3) : 0.0, (unsigned long long) counters[2]);
+	skr_renderer_destroy(renderer);
+	skr_scene_destroy(scene);
+	return 0;
+}

@@ -1,0 +1,395 @@
+// The hot path as one HIP megakernel per launch of row tiles (gfx950 / CDNA4).
+//
+// Replaces the per-pixel loop body reference src/main.cpp:129-182 (== :36-85)
+// and the whole shade() tree under it (src/raytrace.h:139-227, blinn_phong.h,
+// utils.h).  Written from the behaviour, not translated: SoA scene staged in
+// LDS, 64-lane waves own 8x8 pixel tiles, wave-uniform primitive loops with
+// ballot early-outs, counter-based RNG, u8 packing and row-coalesced stores on
+// device.  DESIGN.md describes the layout and the arithmetic spec.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+#include "render_params.h"
+
+namespace {
+
+// Scene as the kernel sees it: pointers into LDS (spheres, materials, lights)
+// and HBM (triangles, read with wave-uniform addresses).
+struct SceneView {
+	const float4 *geom; // LDS  centre.xyz, r*r
+	const float4 *amb;  // LDS  La*ka, .w = phong power
+	const float4 *kd;   // LDS
+	const float4 *ks;   // LDS
+	const float4 *lights; // LDS [2i] position [2i+1] colour
+	const float4 *tris; // HBM  [3i] v0 [3i+1] e1 [3i+2] e2
+	int ns, nt, nl;
+};
+
+struct Counters {
+	uint32_t rays, hits, shadow_rays;
+};
+
+struct RayConst { // per-ray invariants of utils.h:113-121
+	f3 o, d;
+	float two_a, four_a;
+};
+
+SKR_DEV RayConst make_ray(f3 o, f3 d)
+{
+	const float a = dot3(d, d);
+	return RayConst{o, d, 2 * a, 4 * a};
+}
+
+// raytrace.h:152-165: closest accepted sphere (strict <, first index wins ties).
+SKR_DEV int closest_sphere(const SceneView &sv, const RayConst &r, float &tmin)
+{
+	int best = -1;
+	tmin = __builtin_inff();
+	for(int i = 0; i < sv.ns; i++)
+	{
+		const float t = sphere_distance(r.o, r.d, r.two_a, r.four_a, sv.geom[i]);
+		if(accept_distance(t) && t < tmin)
+		{
+			tmin = t;
+			best = i;
+		}
+	}
+	return best;
+}
+
+// raytrace.h:171-186.  The outcome is binary: once a triangle passes with
+// t < min_distance the sample is black (:221-224) whatever comes later, so a
+// lane stops testing at its first accepted triangle and the wave leaves the
+// loop when every active lane has.
+SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float tmin)
+{
+	bool hit = false;
+	for(int i = 0; i < sv.nt; i++)
+	{
+		const f3 v0 = ld3(sv.tris[3 * i]), e1 = ld3(sv.tris[3 * i + 1]), e2 = ld3(sv.tris[3 * i + 2]);
+		float t;
+		if(!hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
+		if((i & 7) == 7 && __all(hit)) break;
+	}
+	return hit;
+}
+
+// utils.h:42-58: any sphere with 1 < t < inf along the (unbounded) shadow ray.
+SKR_DEV bool occluded(const SceneView &sv, f3 P, f3 L)
+{
+	const RayConst r = make_ray(add_scalar(P, 0.000001f), L);
+	bool occ = false;
+	for(int i = 0; i < sv.ns; i++)
+	{
+		if(!occ) occ = accept_distance(sphere_distance(r.o, r.d, r.two_a, r.four_a, sv.geom[i]));
+		if(__all(occ)) break;
+	}
+	return occ;
+}
+
+// raytrace.h:36-44 = bp::ambient (blinn_phong.h:13) + diffuse (:47) + specular (:90).
+// The reference casts the same shadow ray in diffuse and again in specular; one cast serves both.
+SKR_DEV f3 direct_light(const SceneView &sv, const RenderParams &p, int sph, f3 P, f3 N, Counters &cn)
+{
+	const f3 kd = ld3(sv.kd[sph]), ks = ld3(sv.ks[sph]);
+	const float4 ambp = sv.amb[sph];
+	f3 diffuse = mk3(0, 0, 0), specular = mk3(0, 0, 0);
+	const f3 view = normalize3(p.cam_pos - P); // always the camera (blinn_phong.h:93)
+	for(int i = 0; i < sv.nl; i++)
+	{
+		const f3 lp = ld3(sv.lights[2 * i]), lc = ld3(sv.lights[2 * i + 1]);
+		const f3 to_l = lp - P;
+		const float sq = sqr3(to_l);
+		const float len = __fsqrt_rn(sq);
+		const f3 L = to_l * __fdiv_rn(1.0f, len);
+		bool lit = true;
+		if(p.use_shadows)
+		{
+			cn.shadow_rays++;
+			lit = !occluded(sv, P, L);
+		}
+		if(lit)
+		{
+			const float intensity = __fdiv_rn(1.0f, len * len); // 1/powf(|d|,2) == 1/(d*d)
+			diffuse = diffuse + ((kd * lc) * intensity) * max0(dot3(N, L));
+			const f3 vl = view + L;
+			const f3 H = vl / length3(vl);
+			specular = specular + ((ks * lc) * intensity) * powf_spec(max0(dot3(N, H)), ambp.w);
+		}
+	}
+	f3 total = mk3(0, 0, 0);
+	total = total + ld3(ambp);
+	total = total + diffuse;
+	total = total + specular;
+	return total;
+}
+
+// raytrace.h:22-30 + :117-125: hemisphere sample and the reference's basis mix
+// (perp_to_both.y/.z where perp_to_normal.y/.z belongs — kept).
+SKR_DEV f3 gi_direction(float r1, float r2, f3 N, f3 nt, f3 nb)
+{
+	const float s_theta = __fsqrt_rn(1 - r1 * r1);
+	const float phi = (float) ((2.0 * 3.14159265358979323846) * (double) r2); // (2.0f*M_PI)*r2 in double, narrowed
+	float sn, cs;
+	sincos_spec(phi, sn, cs);
+	const float sx = s_theta * cs, sy = r1, sz = s_theta * sn;
+	return mk3((sx * nb.x + sy * N.x) + sz * nt.x,
+			   (sx * nb.y + sy * N.y) + sz * nb.y,
+			   (sx * nb.z + sy * N.z) + sz * nb.z);
+}
+
+// shade() (raytrace.h:139-227) with the recursion depth as a template
+// parameter: LEVELS == the `depth` argument the reference would carry here.
+template <int LEVELS>
+SKR_DEV f3 shade(const SceneView &sv, const RenderParams &p, f3 o, f3 d, uint32_t node, uint32_t pixel, uint32_t aa, Counters &cn)
+{
+	if constexpr(LEVELS <= 0) return mk3(0, 0, 0);
+	else
+	{
+		cn.rays++;
+		const RayConst r = make_ray(o, d);
+		float tmin;
+		const int sph = closest_sphere(sv, r, tmin);
+		if(sv.nt > 0 && any_triangle_closer(sv, r, tmin)) return mk3(0, 0, 0);
+		if(sph < 0) return p.background;
+		cn.hits++;
+		// raytrace.h:197-205: t recomputed for the winner == tmin
+		const f3 P = o + d * tmin;
+		const f3 N = normalize3(P - ld3(sv.geom[sph]));
+		const f3 direct = direct_light(sv, p, sph, P, N, cn);
+		if(!p.monte_carlo) return direct;
+
+		f3 total = mk3(0, 0, 0);
+		if constexpr(LEVELS > 1)
+		{
+			f3 nt, nb;
+			tangent_basis(N, nt, nb);
+			const float pdf = (float) (1 / 3.14159265358979323846);
+			const f3 co = add_scalar(P, 0.00001f);
+			uint32_t rnd[4];
+			for(int i = 0; i < p.num_path_traces; i++)
+			{
+				if((i & 1) == 0) philox4x32_10(pixel, aa, node, (uint32_t) i >> 1, p.seed_lo, p.seed_hi, rnd);
+				const float r1 = u31_to_unit(rnd[2 * (i & 1)]), r2 = u31_to_unit(rnd[2 * (i & 1) + 1]);
+				const f3 w = gi_direction(r1, r2, N, nt, nb);
+				const f3 child = shade<LEVELS - 1>(sv, p, co, w, node * (uint32_t) p.num_path_traces + (uint32_t) i + 1u, pixel, aa, cn);
+				total = total + (child * r1) / pdf;
+			}
+		}
+		// LEVELS == 1: every child is shade(depth 0) == (0,0,0); the sum stays (0,0,0)
+		total = total / (float) p.num_path_traces;
+		return (direct / (float) 3.14159265358979323846 + total * 2.0f) * ld3(sv.kd[sph]);
+	}
+}
+
+SKR_DEV uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+	for(int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+	return v;
+}
+
+} // namespace
+
+// One workgroup = 4 waves = a 16x16 pixel tile; each wave owns an 8x8 sub-tile.
+// Dynamic LDS: scene SoA | 16 rows x 48 bytes of packed RGB for the tile.
+template <int DEPTH>
+__global__ __launch_bounds__(256) void skr_render_kernel(const RenderParams p)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
+	const int ns = p.n_spheres, nl = p.n_lights;
+	float4 *s_geom = lds4, *s_amb = lds4 + ns, *s_kd = lds4 + 2 * ns, *s_ks = lds4 + 3 * ns, *s_lights = lds4 + 4 * ns;
+	unsigned char *s_tile = reinterpret_cast<unsigned char *>(lds4 + 4 * ns + 2 * nl);
+
+	const int tid = threadIdx.x;
+	for(int i = tid; i < ns; i += 256)
+	{
+		s_geom[i] = p.sph_geom[i];
+		s_amb[i] = p.sph_amb[i];
+		s_kd[i] = p.sph_kd[i];
+		s_ks[i] = p.sph_ks[i];
+	}
+	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
+	__syncthreads();
+
+	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl};
+
+	const int wave = tid >> 6, lane = tid & 63;
+	const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
+	const int x = blockIdx.x * 16 + lx;
+	const uint32_t orow = blockIdx.y * 16 + ly;          // row in the compact output
+	const uint32_t k = orow / p.tile_rows;               // which of this launch's tiles
+	const uint32_t y = (p.first_tile + k * p.tile_stride) * p.tile_rows + (orow - k * p.tile_rows);
+	const bool valid = x < p.width && orow < p.out_rows && y < (uint32_t) p.height;
+
+	Counters cn{0, 0, 0};
+	f3 px = mk3(0, 0, 0);
+	if(valid)
+	{
+		const uint32_t pixel = y * (uint32_t) p.width + (uint32_t) x;
+		if(p.grid_size > 0)
+		{ // main.cpp:140-166: g*g samples, one draw r for both axes, all-float
+			const int ns2 = p.grid_size * p.grid_size;
+			for(int s = 0; s < ns2; s++)
+			{
+				uint32_t rnd[4];
+				philox4x32_10(pixel, (uint32_t) s, 0u, 0xFFFFFFFFu, p.seed_lo, p.seed_hi, rnd);
+				const float r = u31_to_unit(rnd[0]);
+				const float u = ((2 * (((float) x + r) * p.inv_width) - 1) * p.angle) * p.aspect;
+				const float v = (1 - 2 * (((float) (int) y + r) * p.inv_height)) * p.angle;
+				const f3 dir = (p.cam_dir + p.cam_right * u) + p.cam_up * v;
+				px = px + shade<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, (uint32_t) s, cn);
+			}
+			px = px / (float) ns2;
+		}
+		else
+		{ // main.cpp:168-182: pixel centre, u and v formed in double then narrowed
+			const float u = (float) (((2 * (((double) x + 0.5) * (double) p.inv_width) - 1) * (double) p.angle) * (double) p.aspect);
+			const float v = (float) ((1 - 2 * (((double) (int) y + 0.5) * (double) p.inv_height)) * (double) p.angle);
+			const f3 dir = (p.cam_dir + p.cam_right * u) + p.cam_up * v;
+			px = shade<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, 0u, cn);
+		}
+		if(p.rgbf)
+		{
+			float *o = p.rgbf + ((size_t) orow * p.width + x) * 3;
+			o[0] = px.x;
+			o[1] = px.y;
+			o[2] = px.z;
+		}
+	}
+
+	// pack to u8 in LDS, then store whole 48-byte row segments as dwords
+	unsigned char *t = s_tile + (ly * 16 + lx) * 3;
+	t[0] = (unsigned char) quantise(px.x);
+	t[1] = (unsigned char) quantise(px.y);
+	t[2] = (unsigned char) quantise(px.z);
+	__syncthreads();
+	if(p.rgb)
+	{
+		const int x0 = blockIdx.x * 16;
+		const bool full = (x0 + 16 <= p.width) && ((p.width & 3) == 0);
+		if(full)
+		{
+			if(tid < 192)
+			{
+				const int row = tid / 12, j = tid - row * 12;
+				const uint32_t orow2 = blockIdx.y * 16 + row;
+				const uint32_t k2 = orow2 / p.tile_rows;
+				const uint32_t y2 = (p.first_tile + k2 * p.tile_stride) * p.tile_rows + (orow2 - k2 * p.tile_rows);
+				if(orow2 < p.out_rows && y2 < (uint32_t) p.height)
+				{
+					uint32_t *dst = reinterpret_cast<uint32_t *>(p.rgb + ((size_t) orow2 * p.width + x0) * 3);
+					dst[j] = reinterpret_cast<const uint32_t *>(s_tile + row * 48)[j];
+				}
+			}
+		}
+		else if(valid)
+		{
+			unsigned char *dst = p.rgb + ((size_t) orow * p.width + x) * 3;
+			dst[0] = t[0];
+			dst[1] = t[1];
+			dst[2] = t[2];
+		}
+	}
+
+	if(p.counters)
+	{
+		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays);
+		if(lane == 0)
+		{
+			atomicAdd(&p.counters[0], (unsigned long long) a);
+			atomicAdd(&p.counters[1], (unsigned long long) b);
+			atomicAdd(&p.counters[2], (unsigned long long) c);
+		}
+	}
+}
+
+// ---------------------------------------------------------------- launch ----
+
+size_t skr_render_lds_bytes(const RenderParams &p) { return ((size_t) 4 * p.n_spheres + 2 * p.n_lights) * 16 + 16 * 48; }
+
+template <int D>
+static hipError_t launch_depth(const RenderParams &p, dim3 grid, size_t lds, hipStream_t stream)
+{
+	hipLaunchKernelGGL(skr_render_kernel<D>, grid, dim3(256), lds, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t skr_launch_render(const RenderParams &p, hipStream_t stream, const char **variant)
+{
+	const dim3 grid((p.width + 15) / 16, (p.out_rows + 15) / 16);
+	const size_t lds = skr_render_lds_bytes(p);
+	*variant = "lane_per_pixel_dfs_v1";
+	switch(p.max_depth)
+	{
+		case 1: return launch_depth<1>(p, grid, lds, stream);
+		case 2: return launch_depth<2>(p, grid, lds, stream);
+		case 3: return launch_depth<3>(p, grid, lds, stream);
+		case 4: return launch_depth<4>(p, grid, lds, stream);
+		case 5: return launch_depth<5>(p, grid, lds, stream);
+		case 6: return launch_depth<6>(p, grid, lds, stream);
+		default: return hipErrorInvalidValue;
+	}
+}
+
+// ------------------------------------------------------------ debug eval ----
+// Device-side evaluation of the arithmetic spec, one record per thread
+// (skr_debug_eval in include/skr.h).
+__global__ void skr_debug_kernel(int op, const uint32_t *in, uint32_t *out, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	auto F = [](uint32_t u) { return __uint_as_float(u); };
+	auto U = [](float f) { return __float_as_uint(f); };
+	switch(op)
+	{
+		case 0: {
+			uint32_t o[4];
+			const uint32_t *c = in + 6 * i;
+			philox4x32_10(c[0], c[1], c[2], c[3], c[4], c[5], o);
+			for(int k = 0; k < 4; k++) out[4 * i + k] = o[k];
+			break;
+		}
+		case 1: {
+			float s, c;
+			sincos_spec(F(in[i]), s, c);
+			out[2 * i] = U(s);
+			out[2 * i + 1] = U(c);
+			break;
+		}
+		case 2: out[i] = U(powf_spec(F(in[2 * i]), F(in[2 * i + 1]))); break;
+		case 3: {
+			const float a = F(in[3 * i]), b = F(in[3 * i + 1]), c = F(in[3 * i + 2]);
+			const float D = b * b - (4 * a) * c;
+			out[i] = U((D < 0) ? __builtin_inff() : near_root_exact(2 * a, b, D));
+			break;
+		}
+		case 4: {
+			const uint32_t *r = in + 15 * i;
+			const f3 o = mk3(F(r[0]), F(r[1]), F(r[2])), d = mk3(F(r[3]), F(r[4]), F(r[5]));
+			const f3 v0 = mk3(F(r[6]), F(r[7]), F(r[8])), v1 = mk3(F(r[9]), F(r[10]), F(r[11])), v2 = mk3(F(r[12]), F(r[13]), F(r[14]));
+			float t = 0.0f;
+			const bool h = triangle_hit(o, d, v0, v1 - v0, v2 - v0, t);
+			out[2 * i] = h ? 1u : 0u;
+			out[2 * i + 1] = h ? U(t) : 0u;
+			break;
+		}
+		case 5: out[i] = quantise(F(in[i])); break;
+		case 6: {
+			f3 nt, nb;
+			tangent_basis(mk3(F(in[3 * i]), F(in[3 * i + 1]), F(in[3 * i + 2])), nt, nb);
+			out[6 * i] = U(nt.x); out[6 * i + 1] = U(nt.y); out[6 * i + 2] = U(nt.z);
+			out[6 * i + 3] = U(nb.x); out[6 * i + 4] = U(nb.y); out[6 * i + 5] = U(nb.z);
+			break;
+		}
+		default: break;
+	}
+}
+
+hipError_t skr_launch_debug(int op, const void *d_in, void *d_out, uint32_t n, hipStream_t stream)
+{
+	hipLaunchKernelGGL(skr_debug_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, (const uint32_t *) d_in, (uint32_t *) d_out, n);
+	return hipGetLastError();
+}

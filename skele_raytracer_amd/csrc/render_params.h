@@ -1,0 +1,29 @@
+// Kernel argument block shared by the launcher (api.cpp) and the kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct f3 {
+	float x, y, z;
+};
+
+struct RenderParams {
+	// image and partition (include/skr.h skr_render_tiles)
+	int32_t width, height;
+	uint32_t tile_rows, first_tile, tile_stride, out_rows;
+	// per-frame invariants of main.cpp:134-137, computed once on the host
+	float inv_width, inv_height, aspect, angle;
+	// camera.h:8-32 (direction/up/right keep the file's magnitudes) and scene.h:24
+	f3 cam_pos, cam_dir, cam_up, cam_right, background;
+	// SoA scene in HBM (scene_host.h)
+	int32_t n_spheres, n_tris, n_lights;
+	const float4 *sph_geom, *sph_amb, *sph_kd, *sph_ks, *lights, *tris;
+	// utils.h:26-34 Options + scene.use_shadows
+	int32_t monte_carlo, num_path_traces, grid_size, max_depth, use_shadows;
+	uint32_t seed_lo, seed_hi;
+	// outputs (device)
+	uint8_t *rgb;
+	float *rgbf;
+	unsigned long long *counters; // [0] radiance rays [1] sphere hits shaded [2] shadow rays
+};

@@ -1,0 +1,365 @@
+// .scn loader, options defaults, PPM writer: the host side of the drop-in
+// boundary.  Behavioural restatement of reference src/scene.cpp:12-227,
+// src/utils.h:26-34 and src/main.cpp:199-211 (citations relative to
+// /root/reference).  No GPU code in this file.
+#include "scene_host.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+
+static thread_local char g_err[512] = "";
+
+void skr_set_error(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+}
+
+extern "C" const char *skr_last_error(void) { return g_err; }
+
+namespace {
+
+// Reads up to n floats the way sscanf("%f ...") does (strtof underneath);
+// fields that are missing stay 0 (the reference leaves them uninitialised).
+int read_floats(const char *p, float *dst, int n)
+{
+	int got = 0;
+	for(; got < n; got++)
+	{
+		char *end = nullptr;
+		float v = strtof(p, &end);
+		if(end == p) break;
+		dst[got] = v;
+		p = end;
+	}
+	return got;
+}
+
+struct Material { // material.h:9-17
+	float ambient[3] = {0, 0, 0}, diffuse[3] = {0, 0, 0}, specular[3] = {0, 0, 0};
+	float power = 1.0f;
+};
+
+} // namespace
+
+void skr_scene::finalize()
+{
+	const int ns = info.n_spheres, nt = info.n_triangles, nl = info.n_point_lights;
+	sph_geom.resize(ns);
+	sph_amb.resize(ns);
+	sph_kd.resize(ns);
+	sph_ks.resize(ns);
+	for(int i = 0; i < ns; i++)
+	{
+		const float *s = &raw_spheres[(size_t) i * 14];
+		sph_geom[i] = {s[0], s[1], s[2], s[3] * s[3]};
+		sph_amb[i] = {info.ambient[0] * s[4], info.ambient[1] * s[5], info.ambient[2] * s[6], s[13]};
+		sph_kd[i] = {s[7], s[8], s[9], 0.0f};
+		sph_ks[i] = {s[10], s[11], s[12], 0.0f};
+	}
+	lights.resize((size_t) nl * 2);
+	for(int i = 0; i < nl; i++)
+	{
+		const float *l = &raw_point_lights[(size_t) i * 6];
+		lights[2 * i] = {l[0], l[1], l[2], 0.0f};
+		lights[2 * i + 1] = {l[3], l[4], l[5], 0.0f};
+	}
+	tris.resize((size_t) nt * 3);
+	for(int i = 0; i < nt; i++)
+	{
+		const float *t = &raw_triangles[(size_t) i * 9];
+		tris[3 * i] = {t[0], t[1], t[2], 0.0f};
+		tris[3 * i + 1] = {t[3] - t[0], t[4] - t[1], t[5] - t[2], 0.0f};
+		tris[3 * i + 2] = {t[6] - t[0], t[7] - t[1], t[8] - t[2], 0.0f};
+	}
+}
+
+static void set_camera(skr_scene_info &info, const float p[3], const float d[3], const float u[3], float ha)
+{
+	for(int k = 0; k < 3; k++)
+	{
+		info.camera[k] = p[k];
+		info.camera[3 + k] = d[k]; // scene.cpp:92-93 discard normalize(): file magnitudes are kept
+		info.camera[6 + k] = u[k];
+	}
+	// camera.h:30: right = cross(direction * -1.0f, up), glm::cross operand order
+	const float nx = d[0] * -1.0f, ny = d[1] * -1.0f, nz = d[2] * -1.0f;
+	info.camera[9] = ny * u[2] - u[1] * nz;
+	info.camera[10] = nz * u[0] - u[2] * nx;
+	info.camera[11] = nx * u[1] - u[0] * ny;
+	info.camera[12] = ha;
+}
+
+int skr_parse_scn(const std::string &path, bool echo, skr_scene &sc)
+{
+	FILE *fp = fopen(path.c_str(), "r");
+	if(!fp)
+	{
+		skr_set_error("Can't open file '%s'", path.c_str()); // scene.cpp:24
+		return SKR_ERR_IO;
+	}
+	sc = skr_scene();
+	skr_scene_info &info = sc.info;
+	info.film_width = 1920; // scene.h:15
+	info.film_height = 1080;
+	info.max_depth_parsed = 1; // scene.h:26
+	Material mat;
+	std::vector<float> verts;
+
+	char line[1024]; // scene.cpp:19: lines are read in 1024-byte pieces
+	while(fgets(line, sizeof line, fp))
+	{
+		if(line[0] == '#')
+		{
+			if(echo) printf("Skipping comment: %s\n", line);
+			continue;
+		}
+		// first whitespace-delimited token = command
+		const char *p = line;
+		while(*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n' || *p == '\v' || *p == '\f') p++;
+		if(!*p) continue;
+		const char *q = p;
+		while(*q && !(*q == ' ' || *q == '\t' || *q == '\r' || *q == '\n' || *q == '\v' || *q == '\f')) q++;
+		const std::string cmd(p, q);
+		const char *args = q;
+
+		if(cmd == "sphere")
+		{
+			float v[4] = {0, 0, 0, 0};
+			read_floats(args, v, 4);
+			if(echo) printf("Sphere as position (%f, %f, %f) with radius %f\n", v[0], v[1], v[2], v[3]);
+			const float rec[14] = {v[0], v[1], v[2], v[3], mat.ambient[0], mat.ambient[1], mat.ambient[2],
+								   mat.diffuse[0], mat.diffuse[1], mat.diffuse[2], mat.specular[0], mat.specular[1], mat.specular[2], mat.power};
+			sc.raw_spheres.insert(sc.raw_spheres.end(), rec, rec + 14);
+			info.n_spheres++;
+		}
+		else if(cmd == "vertex")
+		{
+			float v[3] = {0, 0, 0};
+			read_floats(args, v, 3);
+			verts.insert(verts.end(), v, v + 3);
+			info.n_vertices++;
+		}
+		else if(cmd == "triangle")
+		{
+			float v[3] = {0, 0, 0}; // scene.cpp:69-70: indices are read as floats
+			read_floats(args, v, 3);
+			long idx[3] = {(long) v[0], (long) v[1], (long) v[2]};
+			bool ok = true;
+			for(long i : idx) ok = ok && i >= 0 && i < info.n_vertices;
+			if(!ok)
+			{ // the reference reads out of bounds here; no shipped scene does
+				fprintf(stderr, "WARNING. triangle references a vertex outside the pool (%d vertices so far): skipped\n", info.n_vertices);
+				info.n_bad_triangles++;
+				continue;
+			}
+			for(long i : idx) sc.raw_triangles.insert(sc.raw_triangles.end(), &verts[(size_t) i * 3], &verts[(size_t) i * 3] + 3);
+			info.n_triangles++;
+		}
+		else if(cmd == "camera")
+		{
+			float v[10] = {0};
+			read_floats(args, v, 10);
+			if(echo)
+				printf("Camera with position (%f, %f, %f) with viewing direction (%f, %f, %f), up glm::vec3 (%f, %f, %f), and halfHeightAngle %f\n",
+					   v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);
+			set_camera(info, v, v + 3, v + 6, v[9]);
+			// (the reference also drops a "simplesphere.txt" camera dump into the CWD here,
+			//  scene.cpp:96-102 — a debugging leftover that is deliberately not reproduced)
+		}
+		else if(cmd == "film_resolution")
+		{
+			int w = info.film_width, h = info.film_height;
+			sscanf(args, "%d %d", &w, &h);
+			info.film_width = w;
+			info.film_height = h;
+			if(echo) printf("Film resolution: %d x %d\n", w, h);
+		}
+		else if(cmd == "background")
+		{
+			float v[3] = {0, 0, 0};
+			read_floats(args, v, 3);
+			if(echo) printf("Background color of (%f,%f,%f)\n", v[0], v[1], v[2]);
+			memcpy(info.background, v, sizeof v);
+		}
+		else if(cmd == "material")
+		{
+			float v[14] = {0};
+			read_floats(args, v, 14);
+			if(echo)
+				printf("material properties with ambient colour (%f, %f, %f), diffuse colour (%f, %f, %f), specular colour (%f, %f, %f), phong Cosine power %f, transmissive colour (%f, %f, %f), index of refraction %f\n",
+					   v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12], v[13]);
+			memcpy(mat.ambient, v, 12);
+			memcpy(mat.diffuse, v + 3, 12);
+			memcpy(mat.specular, v + 6, 12);
+			mat.power = v[9]; // transmissive colour and ior feed only dead code (raytrace.h:45-103)
+		}
+		else if(cmd == "directional_light")
+		{
+			float v[6] = {0};
+			read_floats(args, v, 6);
+			if(echo) printf("directional light colour (%f, %f, %f), direction (%f, %f, %f)\n", v[0], v[1], v[2], v[3], v[4], v[5]);
+			info.n_directional_dropped++; // scene.cpp:157-163: built, never pushed
+		}
+		else if(cmd == "point_light")
+		{
+			float v[6] = {0};
+			read_floats(args, v, 6);
+			if(echo) printf("point light colour (%f, %f, %f), located at (%f, %f, %f)\n", v[0], v[1], v[2], v[3], v[4], v[5]);
+			const float rec[6] = {v[3], v[4], v[5], v[0], v[1], v[2]}; // file order is colour then position
+			sc.raw_point_lights.insert(sc.raw_point_lights.end(), rec, rec + 6);
+			info.n_point_lights++;
+		}
+		else if(cmd == "ambient_light")
+		{
+			float v[3] = {0, 0, 0};
+			read_floats(args, v, 3);
+			if(echo) printf("Ambient light colour (%f, %f, %f)\n", v[0], v[1], v[2]);
+			for(int k = 0; k < 3; k++) info.ambient[k] += v[k]; // scene.cpp:187-189 accumulates
+		}
+		else if(cmd == "max_depth")
+		{
+			float n = 0;
+			read_floats(args, &n, 1);
+			if(echo) printf("max_depth %f\n", n);
+			info.max_depth_parsed = (int) n;
+		}
+		else if(cmd == "output_image")
+		{
+			if(echo) printf("Render to file named: %s", args + (*args ? 1 : 0));
+		}
+		else if(cmd == "spherical_fog")
+		{
+			// scene.cpp:207-212 pushes a fog volume built from uninitialised floats
+			// (sscanf "fog ..." never matches): undefined behaviour, pinned as "ignored".
+			fprintf(stderr, "WARNING. spherical_fog is not reproducible in the reference (uninitialised data): line skipped\n");
+			info.n_fog_skipped++;
+		}
+		else
+		{
+			if(echo) printf("WARNING. Do not know command: %s\n", cmd.c_str());
+			info.n_unknown++;
+		}
+	}
+	fclose(fp);
+	sc.finalize();
+	return SKR_OK;
+}
+
+extern "C" {
+
+int skr_scene_create_from_scn(const char *path, int echo, skr_scene **out)
+{
+	if(!path || !out)
+	{
+		skr_set_error("skr_scene_create_from_scn: null argument");
+		return SKR_ERR_ARG;
+	}
+	skr_scene *sc = new skr_scene();
+	int rc = skr_parse_scn(path, echo != 0, *sc);
+	if(rc != SKR_OK)
+	{
+		delete sc;
+		*out = nullptr;
+		return rc;
+	}
+	*out = sc;
+	return SKR_OK;
+}
+
+int skr_scene_create_from_arrays(const float *spheres, int32_t n_spheres, const float *triangles, int32_t n_triangles,
+								 const float *point_lights, int32_t n_point_lights, const float camera[9],
+								 const float background[3], const float ambient[3], skr_scene **out)
+{
+	if(!out || !camera || n_spheres < 0 || n_triangles < 0 || n_point_lights < 0 || (n_spheres && !spheres) ||
+	   (n_triangles && !triangles) || (n_point_lights && !point_lights))
+	{
+		skr_set_error("skr_scene_create_from_arrays: bad argument");
+		return SKR_ERR_ARG;
+	}
+	skr_scene *sc = new skr_scene();
+	sc->info.film_width = 1920;
+	sc->info.film_height = 1080;
+	sc->info.max_depth_parsed = 1;
+	sc->info.n_spheres = n_spheres;
+	sc->info.n_triangles = n_triangles;
+	sc->info.n_point_lights = n_point_lights;
+	sc->raw_spheres.assign(spheres, spheres + (size_t) n_spheres * 14);
+	sc->raw_triangles.assign(triangles, triangles + (size_t) n_triangles * 9);
+	sc->raw_point_lights.assign(point_lights, point_lights + (size_t) n_point_lights * 6);
+	set_camera(sc->info, camera, camera + 3, camera + 6, 0.0f);
+	if(background) memcpy(sc->info.background, background, 12);
+	if(ambient) memcpy(sc->info.ambient, ambient, 12);
+	sc->finalize();
+	*out = sc;
+	return SKR_OK;
+}
+
+void skr_scene_destroy(skr_scene *scene) { delete scene; }
+
+int skr_scene_get_info(const skr_scene *scene, skr_scene_info *info)
+{
+	if(!scene || !info) return SKR_ERR_ARG;
+	*info = scene->info;
+	return SKR_OK;
+}
+
+int skr_scene_get_arrays(const skr_scene *scene, float *spheres, float *triangles, float *point_lights)
+{
+	if(!scene) return SKR_ERR_ARG;
+	if(spheres && !scene->raw_spheres.empty()) memcpy(spheres, scene->raw_spheres.data(), scene->raw_spheres.size() * 4);
+	if(triangles && !scene->raw_triangles.empty()) memcpy(triangles, scene->raw_triangles.data(), scene->raw_triangles.size() * 4);
+	if(point_lights && !scene->raw_point_lights.empty()) memcpy(point_lights, scene->raw_point_lights.data(), scene->raw_point_lights.size() * 4);
+	return SKR_OK;
+}
+
+void skr_options_default(skr_options *opt)
+{
+	if(!opt) return;
+	opt->width = 1920; // scene.h:15
+	opt->height = 1080;
+	opt->fov = 60; // utils.h:28-33
+	opt->monte_carlo = 0;
+	opt->num_path_traces = 1;
+	opt->grid_size = 0;
+	opt->max_depth = 3;
+	opt->use_shadows = 0;
+	opt->seed = 1;
+}
+
+uint64_t skr_radiance_ray_count(const skr_options *opt)
+{
+	if(!opt || opt->width <= 0 || opt->height <= 0) return 0;
+	const uint64_t S = opt->grid_size > 0 ? (uint64_t) opt->grid_size * opt->grid_size : 1;
+	uint64_t per = 0, pw = 1;
+	for(int k = 0; k < opt->max_depth; k++)
+	{
+		per += pw;
+		if(!opt->monte_carlo) break;
+		pw *= (uint64_t) (opt->num_path_traces > 0 ? opt->num_path_traces : 0);
+	}
+	return (uint64_t) opt->width * opt->height * S * per;
+}
+
+// main.cpp:199-211: "P6\n" W " " H "\n255\n" then W*H*3 bytes, top row first.
+int skr_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb)
+{
+	if(!path || !rgb) return SKR_ERR_ARG;
+	std::ofstream ofs(path, std::ios::out | std::ios::binary);
+	if(!ofs)
+	{
+		skr_set_error("cannot open '%s' for writing", path);
+		return SKR_ERR_IO;
+	}
+	ofs << "P6\n" << width << " " << height << "\n255\n";
+	ofs.write(reinterpret_cast<const char *>(rgb), (std::streamsize) width * height * 3);
+	ofs.close();
+	return ofs ? SKR_OK : SKR_ERR_IO;
+}
+
+} // extern "C"

@@ -1,0 +1,38 @@
+// Host-side scene: what the .scn loader produces and what is uploaded to HBM.
+// Replaces struct Scene (reference src/scene.h:13-28) and its AoS members
+// (shapes.h:12,26  material.h:9  lights.h:19  camera.h:8) with the SoA layout the
+// kernels read.  See DESIGN.md "Data layout in HBM".
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/skr.h"
+
+struct skr_f4 {
+	float x, y, z, w;
+};
+
+struct skr_scene {
+	// raw values as parsed (skr_scene_get_arrays, loader parity tests)
+	std::vector<float> raw_spheres;      // [n][14] centre radius ambient diffuse specular power
+	std::vector<float> raw_triangles;    // [n][9]  v0 v1 v2
+	std::vector<float> raw_point_lights; // [n][6]  position colour
+	skr_scene_info info{};
+
+	// SoA arrays as uploaded (built by finalize())
+	std::vector<skr_f4> sph_geom; // centre.xyz, radius*radius (utils.h:118 forms r*r per test; same product)
+	std::vector<skr_f4> sph_amb;  // ambient_light.colour * material.ambient (blinn_phong.h:15), .w = phong power
+	std::vector<skr_f4> sph_kd;   // material.diffuse
+	std::vector<skr_f4> sph_ks;   // material.specular
+	std::vector<skr_f4> lights;   // [2*i] position, [2*i+1] colour
+	std::vector<skr_f4> tris;     // [3*i] v0, [3*i+1] v1-v0, [3*i+2] v2-v0 (utils.h:183-184 subtractions)
+
+	void finalize();
+};
+
+// scene.cpp:12-227 replacement.  Returns SKR_OK or SKR_ERR_IO.
+int skr_parse_scn(const std::string &path, bool echo, skr_scene &out);
+
+void skr_set_error(const char *fmt, ...);
