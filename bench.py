@@ -32,16 +32,16 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
 
 
-def cpu_baseline(nominal_per_pixel):
-    """The oracle (CPU restatement, counter RNG, OpenMP over rows) timed on this box's host cores
-    on a bounded, representative sample of the same frame: every 8th 8-row tile."""
+def cpu_baseline():
+    """The oracle (CPU restatement, counter RNG, OpenMP over (row, 32-pixel span) items) timed on this
+    box's host cores on a bounded, representative sample of the same frame: every 4th 8-row tile."""
     from oracle import pyoracle as orc
-    cores = len(os.sched_getaffinity(0))
+    cores = orc.host_cores()
     scene = orc.OracleScene(SCENE)
     rays = 0
-    t0 = time.perf_counter()
     rows = 0
-    for t in range(0, (H + TILE_ROWS - 1) // TILE_ROWS, 8):
+    t0 = time.perf_counter()
+    for t in range(0, (H + TILE_ROWS - 1) // TILE_ROWS, 4):
         y0, y1 = t * TILE_ROWS, min(H, (t + 1) * TILE_ROWS)
         _, _, st = orc.render(scene, W, H, rng=orc.RNG_COUNTER, math=orc.MATH_SHARED, y0=y0, y1=y1, threads=cores,
                               gillum=KW["gillum"], shadow=KW["shadow"], depth=KW["depth"], seed=KW["seed"])
@@ -49,8 +49,8 @@ def cpu_baseline(nominal_per_pixel):
         rows += y1 - y0
     dt = time.perf_counter() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "oracle/liboracle.so (OpenMP, %d threads), rows of every 8th %d-row tile of the same frame: %d rows, %d radiance rays in %.2f s"
-                      % (cores, TILE_ROWS, rows, rays, dt)}
+            "sample": "oracle/liboracle.so (C restatement, -O2, OpenMP %d threads = cgroup CPU quota), every 4th %d-row tile of the same "
+                      "frame: %d rows, %d radiance rays in %.2f s" % (cores, TILE_ROWS, rows, rays, dt)}
 
 
 def main():
@@ -165,7 +165,7 @@ def main():
                               "note": "algorithmic flops (34/sphere test, 150/shaded hit; shadow early-outs ignored) per GPU / peak FP32 vector"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(None)
+            out["cpu_baseline"] = cpu_baseline()
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -103,6 +103,18 @@ class OracleScene:
             pass
 
 
+def host_cores():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(-(-int(quota) // int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def render(scene, width, height, *, fov=60.0, gillum=None, jsample=0, depth=3, shadow=False,
            rng=RNG_COUNTER, math=MATH_SHARED, seed=1, y0=0, y1=None, threads=None, want_float=False):
     """Returns (rgb uint8 [rows,W,3], float image or None, stats uint64[5])."""
@@ -110,7 +122,7 @@ def render(scene, width, height, *, fov=60.0, gillum=None, jsample=0, depth=3, s
         scene = OracleScene(scene)
     y1 = height if y1 is None else y1
     o = Options(width, height, fov, 0 if gillum is None else 1, 1 if gillum is None else gillum, jsample,
-                depth, int(bool(shadow)), rng, math, seed, y0, y1, threads or (os.cpu_count() or 1))
+                depth, int(bool(shadow)), rng, math, seed, y0, y1, threads or host_cores())
     rows = y1 - y0
     rgb = np.zeros((rows, width, 3), np.uint8)
     rgbf = np.zeros((rows, width, 3), np.float32) if want_float else None

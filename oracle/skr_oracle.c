@@ -493,13 +493,21 @@ int sko_render(const sko_scene *scene, const sko_options *opt, uint8_t *rgb, flo
 
 	/* replay mode must visit every row from 0 so the rand() stream lines up */
 	const int ystart = (opt->rng_mode == SKO_RNG_GLIBC_REPLAY && uses_rand) ? 0 : opt->y0;
+	/* work items = (row, 32-pixel span), handed out dynamically: rows differ a lot in cost
+	 * (sky vs ground) and a band may have fewer rows than there are threads */
+	const int span = 32;
+	const int spans_per_row = (W + span - 1) / span;
+	const long n_items = (long) (opt->y1 - ystart) * spans_per_row;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : tot[:5])
 #endif
-	for(int y = ystart; y < opt->y1; y++)
+	for(long item = 0; item < n_items; item++)
 	{
+		const int y = ystart + (int) (item / spans_per_row);
+		const int xs = (int) (item % spans_per_row) * span;
+		const int xe = (xs + span < W) ? xs + span : W;
 		ctx_t cx = {scene, opt, 0, 0, 0, 0, 0, 0, 0};
-		for(int x = 0; x < W; x++)
+		for(int x = xs; x < xe; x++)
 		{
 			v3 px = V(0, 0, 0);
 			cx.pixel = (uint32_t) y * (uint32_t) W + (uint32_t) x;

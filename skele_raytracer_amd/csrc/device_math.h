@@ -15,21 +15,27 @@
 
 #define SKR_DEV static __device__ __forceinline__
 
+// Correctly rounded binary32 sqrt and divide.  NOT __fsqrt_rn/__fdiv_rn: in this ROCm's
+// __clang_hip_math.h __fsqrt_rn is __ocml_native_sqrt_f32 (approximate).  Plain sqrtf and `/`
+// are IEEE-correct under -fhip-fp32-correctly-rounded-divide-sqrt (tests/test_gpu_units.py).
+SKR_DEV float sk_sqrtf(float x) { return __builtin_sqrtf(x); }
+SKR_DEV float sk_divf(float a, float b) { return a / b; }
+
 SKR_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
 SKR_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 SKR_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 SKR_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 SKR_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
-SKR_DEV f3 operator/(f3 a, float s) { return mk3(__fdiv_rn(a.x, s), __fdiv_rn(a.y, s), __fdiv_rn(a.z, s)); } // glm: per-component divide
+SKR_DEV f3 operator/(f3 a, float s) { return mk3(sk_divf(a.x, s), sk_divf(a.y, s), sk_divf(a.z, s)); } // glm: per-component divide
 SKR_DEV f3 add_scalar(f3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
 // glm::dot for vec3: (x + y) + z of the component products (func_geometric.inl:66-73)
 SKR_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 // glm::cross operand order (func_geometric.inl:216-226)
 SKR_DEV f3 cross3(f3 x, f3 y) { return mk3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
 SKR_DEV float sqr3(f3 v) { return (v.x * v.x + v.y * v.y) + v.z * v.z; }
-SKR_DEV float length3(f3 v) { return __fsqrt_rn(sqr3(v)); }
+SKR_DEV float length3(f3 v) { return sk_sqrtf(sqr3(v)); }
 // glm::normalize: v * (1.0f / sqrt(sum)) (func_geometric.inl:253-261, func_exponential.inl:226-229)
-SKR_DEV f3 normalize3(f3 v) { return v * __fdiv_rn(1.0f, __fsqrt_rn(sqr3(v))); }
+SKR_DEV f3 normalize3(f3 v) { return v * sk_divf(1.0f, sk_sqrtf(sqr3(v))); }
 // std::max(0.0f, x): NaN -> 0
 SKR_DEV float max0(float x) { return (0.0f < x) ? x : 0.0f; }
 SKR_DEV f3 ld3(const float4 v) { return mk3(v.x, v.y, v.z); }
@@ -185,7 +191,7 @@ SKR_DEV bool triangle_hit(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float &t)
 	const f3 p = cross3(d, e2);
 	const float det = dot3(e1, p);
 	if(fabsf(det) < 0.00001f) return false;
-	const float inv = __fdiv_rn(1.0f, det);
+	const float inv = sk_divf(1.0f, det);
 	const f3 tv = o - v0;
 	const float u = inv * dot3(mk3(-tv.x, -tv.y, -tv.z), p);
 	if(u < 0 || u > 1) return false;
@@ -199,8 +205,8 @@ SKR_DEV bool triangle_hit(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float &t)
 // utils.h:148-165 transform_coordinate_space
 SKR_DEV void tangent_basis(f3 n, f3 &nt, f3 &nb)
 {
-	if(fabsf(n.x) > fabsf(n.y)) nt = mk3(n.z, 0.0f, -n.x) / __fsqrt_rn(n.x * n.x + n.z * n.z);
-	else nt = mk3(0.0f, -n.z, n.y) / __fsqrt_rn(n.y * n.y + n.z * n.z);
+	if(fabsf(n.x) > fabsf(n.y)) nt = mk3(n.z, 0.0f, -n.x) / sk_sqrtf(n.x * n.x + n.z * n.z);
+	else nt = mk3(0.0f, -n.z, n.y) / sk_sqrtf(n.y * n.y + n.z * n.z);
 	nb = cross3(n, nt);
 }
 

@@ -101,8 +101,8 @@ SKR_DEV f3 direct_light(const SceneView &sv, const RenderParams &p, int sph, f3 
 		const f3 lp = ld3(sv.lights[2 * i]), lc = ld3(sv.lights[2 * i + 1]);
 		const f3 to_l = lp - P;
 		const float sq = sqr3(to_l);
-		const float len = __fsqrt_rn(sq);
-		const f3 L = to_l * __fdiv_rn(1.0f, len);
+		const float len = sk_sqrtf(sq);
+		const f3 L = to_l * sk_divf(1.0f, len);
 		bool lit = true;
 		if(p.use_shadows)
 		{
@@ -111,7 +111,7 @@ SKR_DEV f3 direct_light(const SceneView &sv, const RenderParams &p, int sph, f3 
 		}
 		if(lit)
 		{
-			const float intensity = __fdiv_rn(1.0f, len * len); // 1/powf(|d|,2) == 1/(d*d)
+			const float intensity = sk_divf(1.0f, len * len); // 1/powf(|d|,2) == 1/(d*d)
 			diffuse = diffuse + ((kd * lc) * intensity) * max0(dot3(N, L));
 			const f3 vl = view + L;
 			const f3 H = vl / length3(vl);
@@ -129,7 +129,7 @@ SKR_DEV f3 direct_light(const SceneView &sv, const RenderParams &p, int sph, f3 
 // (perp_to_both.y/.z where perp_to_normal.y/.z belongs — kept).
 SKR_DEV f3 gi_direction(float r1, float r2, f3 N, f3 nt, f3 nb)
 {
-	const float s_theta = __fsqrt_rn(1 - r1 * r1);
+	const float s_theta = sk_sqrtf(1 - r1 * r1);
 	const float phi = (float) ((2.0 * 3.14159265358979323846) * (double) r2); // (2.0f*M_PI)*r2 in double, narrowed
 	float sn, cs;
 	sincos_spec(phi, sn, cs);
@@ -382,6 +382,11 @@ __global__ void skr_debug_kernel(int op, const uint32_t *in, uint32_t *out, uint
 			tangent_basis(mk3(F(in[3 * i]), F(in[3 * i + 1]), F(in[3 * i + 2])), nt, nb);
 			out[6 * i] = U(nt.x); out[6 * i + 1] = U(nt.y); out[6 * i + 2] = U(nt.z);
 			out[6 * i + 3] = U(nb.x); out[6 * i + 4] = U(nb.y); out[6 * i + 5] = U(nb.z);
+			break;
+		}
+		case 7: { // binary32 sqrt and divide must be the correctly rounded forms
+			out[2 * i] = U(sk_sqrtf(F(in[2 * i])));
+			out[2 * i + 1] = U(sk_divf(F(in[2 * i]), F(in[2 * i + 1])));
 			break;
 		}
 		default: break;

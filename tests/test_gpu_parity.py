@@ -34,6 +34,7 @@ def renderer(scn):
 
 def gpu_render(scn, w, h, want_float=True, **kw):
     r = renderer(scn)
+    r.counters(reset=True)  # renderers are cached across tests: drop what earlier launches accumulated
     rgb, rgbf = r.render(skr.Options(w, h, **kw), want_float=want_float)
     import torch
     torch.cuda.synchronize()

@@ -108,3 +108,14 @@ def test_quantise_and_basis(oracle):
     for i in range(0, 4000, 5):
         L.sko_basis((C.c_float * 3)(*nrm[i].tolist()), nt, nb)
         assert np.array_equal(ob[i], f32(list(nt) + list(nb)).view(np.uint32))
+
+
+def test_float_sqrt_and_divide_are_correctly_rounded():
+    a = np.concatenate([RNG.random(100000).astype(np.float32) * 1000, f32([0, 1, 2, 3, 1e-40, 1e38, 0.1])])
+    b = np.concatenate([(RNG.random(100000).astype(np.float32) - 0.5) * 50, f32([1, 3, 7, 0.1, 3, 1e-3, 3])])
+    out = binding.debug_eval(7, np.stack([a, b], 1), 2)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want_s = np.sqrt(a.astype(np.float64)).astype(np.float32)   # sqrt of a float in double, rounded once == correctly rounded
+        want_d = (a.astype(np.float64) / b.astype(np.float64)).astype(np.float32)  # double quotient of floats rounds correctly (53 >= 2*24+2)
+    assert np.array_equal(out[:, 0], want_s.view(np.uint32))
+    assert np.array_equal(out[:, 1], want_d.view(np.uint32))
