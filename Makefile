@@ -10,9 +10,9 @@ LIBDIR  := skele_raytracer_amd/lib
 # float divide/sqrt stay correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
             -fno-fast-math -Wall -Wno-unused-function -Iinclude
-KERNEL_SRCS := $(CSRC)/render_kernel.hip
+KERNEL_SRCS := $(CSRC)/render_kernel.hip $(CSRC)/render_wave.hip
 HOST_SRCS   := $(CSRC)/api.cpp $(CSRC)/scene_host.cpp
-HDRS        := include/skr.h $(CSRC)/device_math.h $(CSRC)/render_params.h $(CSRC)/scene_host.h
+HDRS        := include/skr.h $(CSRC)/device_math.h $(CSRC)/shade_common.h $(CSRC)/render_params.h $(CSRC)/scene_host.h
 
 all: lib cli oracle
 
@@ -32,7 +32,8 @@ oracle:
 
 asm: $(KERNEL_SRCS) $(HDRS)
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S -o build/render_kernel.s $(KERNEL_SRCS) -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt
+	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S -o build/render_kernel.s $(CSRC)/render_kernel.hip -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt
+	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S -o build/render_wave.s $(CSRC)/render_wave.hip -Rpass-analysis=kernel-resource-usage 2>> build/resource_usage.txt
 
 clean:
 	rm -rf $(LIBDIR) bin build

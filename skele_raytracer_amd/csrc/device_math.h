@@ -184,6 +184,69 @@ SKR_DEV float sphere_distance(f3 o, f3 d, float two_a, float four_a, float4 sph)
 // utils.h:169-179
 SKR_DEV bool accept_distance(float t) { return !(t <= 1.0f || t == __builtin_inff()); }
 
+// ------------------------------------------------ filtered predicates ----
+// The reference decides "1 < t < inf" and orders candidates by
+//   t2 = fl32( fl64( fl64(-b - fl64(sqrt(D))) / (2a) ) )          (utils.h:87-110)
+// which costs a binary64 sqrt and divide per candidate sphere.  The kernels first
+// bracket t2 with binary32 arithmetic: with s = v_sqrt_f32(D), num = fl32(-b - s),
+// ta = fl32(num * rcp(2a)) (v_sqrt/v_rcp are 1-ulp instructions) every rounding is a
+// relative perturbation <= 2^-22 of s, num or the quotient, so
+//   |ta - t2| <= E = (s + |num|) * rcp(2a) * 2^-20 + |ta| * 2^-22
+// with a factor >= 4 to spare (DESIGN.md "Filtered predicates" has the derivation).
+// A decision is taken from [ta-E, ta+E] only when the whole interval is on one side;
+// otherwise (and whenever a NaN/inf/denormal shows up: every comparison below is
+// written so that NaN falls through) the exact binary64 form is evaluated.  Results
+// are therefore identical to evaluating the exact form everywhere.
+struct RayFilt {
+	float two_a, four_a; // exact per-ray invariants (2a, 4a)
+	float inv2a;         // ~ 1/(2a)
+	float k_err;         // inv2a * 2^-20
+	bool sane;           // a in a range where the relative bounds hold
+};
+
+SKR_DEV RayFilt make_filt(f3 d)
+{
+	const float a = dot3(d, d);
+	RayFilt f;
+	f.two_a = 2 * a;
+	f.four_a = 4 * a;
+	f.inv2a = __builtin_amdgcn_rcpf(f.two_a);
+	f.k_err = f.inv2a * 0x1p-20f;
+	f.sane = (a > 1e-18f) && (a < 1e18f);
+	return f;
+}
+
+// One sphere against one ray.  Returns false for a certain miss.  Otherwise
+// [lo, hi] brackets t2 (lo == hi when it had to be resolved exactly) and b, D
+// are the spec's float coefficients (kept for the exact evaluation of the winner).
+SKR_DEV bool sphere_bracket(f3 o, f3 d, const RayFilt &f, float4 sph, float &lo, float &hi, float &b, float &D)
+{
+	const f3 e = o - ld3(sph);
+	b = 2 * dot3(d, e);
+	const float c = dot3(e, e) - sph.w;
+	D = b * b - f.four_a * c;
+	// b >= 0 => -b - sqrt(D) <= 0 => t2 <= 0 (or NaN): never accepted.  D < 0 / NaN: miss.
+	if(!(D >= 0.0f) || !(b < 0.0f)) return false;
+	const float s = __builtin_amdgcn_sqrtf(D);
+	const float num = (-b) - s;
+	const float ta = num * f.inv2a;
+	const float E = __builtin_fmaf(__builtin_fabsf(ta), 0x1p-22f, (s + __builtin_fabsf(num)) * f.k_err);
+	lo = ta - E;
+	hi = ta + E;
+	const bool normal = f.sane && (D > 1e-30f) && (b < -1e-15f);
+	const bool certain_accept = normal && (lo > 1.0f) && (hi < 3.0e38f);
+	const bool certain_reject = normal && (hi < 1.0f);
+	if(certain_reject) return false;
+	if(!certain_accept)
+	{ // too close to call in binary32: the exact form decides
+		const float t = near_root_exact(f.two_a, b, D);
+		if(!accept_distance(t)) return false;
+		lo = hi = t;
+	}
+	return true;
+}
+
+
 // utils.h:181-213 with the edges e1 = v1-v0, e2 = v2-v0 precomputed on the host
 // (same subtractions).  u carries the reference's flipped sign; no t>0 test.
 SKR_DEV bool triangle_hit(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float &t)

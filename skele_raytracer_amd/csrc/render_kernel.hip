@@ -8,136 +8,12 @@
 // device.  DESIGN.md describes the layout and the arithmetic spec.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
-#include "device_math.h"
-#include "render_params.h"
+#include "shade_common.h"
 
 namespace {
-
-// Scene as the kernel sees it: pointers into LDS (spheres, materials, lights)
-// and HBM (triangles, read with wave-uniform addresses).
-struct SceneView {
-	const float4 *geom; // LDS  centre.xyz, r*r
-	const float4 *amb;  // LDS  La*ka, .w = phong power
-	const float4 *kd;   // LDS
-	const float4 *ks;   // LDS
-	const float4 *lights; // LDS [2i] position [2i+1] colour
-	const float4 *tris; // HBM  [3i] v0 [3i+1] e1 [3i+2] e2
-	int ns, nt, nl;
-};
-
-struct Counters {
-	uint32_t rays, hits, shadow_rays;
-};
-
-struct RayConst { // per-ray invariants of utils.h:113-121
-	f3 o, d;
-	float two_a, four_a;
-};
-
-SKR_DEV RayConst make_ray(f3 o, f3 d)
-{
-	const float a = dot3(d, d);
-	return RayConst{o, d, 2 * a, 4 * a};
-}
-
-// raytrace.h:152-165: closest accepted sphere (strict <, first index wins ties).
-SKR_DEV int closest_sphere(const SceneView &sv, const RayConst &r, float &tmin)
-{
-	int best = -1;
-	tmin = __builtin_inff();
-	for(int i = 0; i < sv.ns; i++)
-	{
-		const float t = sphere_distance(r.o, r.d, r.two_a, r.four_a, sv.geom[i]);
-		if(accept_distance(t) && t < tmin)
-		{
-			tmin = t;
-			best = i;
-		}
-	}
-	return best;
-}
-
-// raytrace.h:171-186.  The outcome is binary: once a triangle passes with
-// t < min_distance the sample is black (:221-224) whatever comes later, so a
-// lane stops testing at its first accepted triangle and the wave leaves the
-// loop when every active lane has.
-SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float tmin)
-{
-	bool hit = false;
-	for(int i = 0; i < sv.nt; i++)
-	{
-		const f3 v0 = ld3(sv.tris[3 * i]), e1 = ld3(sv.tris[3 * i + 1]), e2 = ld3(sv.tris[3 * i + 2]);
-		float t;
-		if(!hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
-		if((i & 7) == 7 && __all(hit)) break;
-	}
-	return hit;
-}
-
-// utils.h:42-58: any sphere with 1 < t < inf along the (unbounded) shadow ray.
-SKR_DEV bool occluded(const SceneView &sv, f3 P, f3 L)
-{
-	const RayConst r = make_ray(add_scalar(P, 0.000001f), L);
-	bool occ = false;
-	for(int i = 0; i < sv.ns; i++)
-	{
-		if(!occ) occ = accept_distance(sphere_distance(r.o, r.d, r.two_a, r.four_a, sv.geom[i]));
-		if(__all(occ)) break;
-	}
-	return occ;
-}
-
-// raytrace.h:36-44 = bp::ambient (blinn_phong.h:13) + diffuse (:47) + specular (:90).
-// The reference casts the same shadow ray in diffuse and again in specular; one cast serves both.
-SKR_DEV f3 direct_light(const SceneView &sv, const RenderParams &p, int sph, f3 P, f3 N, Counters &cn)
-{
-	const f3 kd = ld3(sv.kd[sph]), ks = ld3(sv.ks[sph]);
-	const float4 ambp = sv.amb[sph];
-	f3 diffuse = mk3(0, 0, 0), specular = mk3(0, 0, 0);
-	const f3 view = normalize3(p.cam_pos - P); // always the camera (blinn_phong.h:93)
-	for(int i = 0; i < sv.nl; i++)
-	{
-		const f3 lp = ld3(sv.lights[2 * i]), lc = ld3(sv.lights[2 * i + 1]);
-		const f3 to_l = lp - P;
-		const float sq = sqr3(to_l);
-		const float len = sk_sqrtf(sq);
-		const f3 L = to_l * sk_divf(1.0f, len);
-		bool lit = true;
-		if(p.use_shadows)
-		{
-			cn.shadow_rays++;
-			lit = !occluded(sv, P, L);
-		}
-		if(lit)
-		{
-			const float intensity = sk_divf(1.0f, len * len); // 1/powf(|d|,2) == 1/(d*d)
-			diffuse = diffuse + ((kd * lc) * intensity) * max0(dot3(N, L));
-			const f3 vl = view + L;
-			const f3 H = vl / length3(vl);
-			specular = specular + ((ks * lc) * intensity) * powf_spec(max0(dot3(N, H)), ambp.w);
-		}
-	}
-	f3 total = mk3(0, 0, 0);
-	total = total + ld3(ambp);
-	total = total + diffuse;
-	total = total + specular;
-	return total;
-}
-
-// raytrace.h:22-30 + :117-125: hemisphere sample and the reference's basis mix
-// (perp_to_both.y/.z where perp_to_normal.y/.z belongs — kept).
-SKR_DEV f3 gi_direction(float r1, float r2, f3 N, f3 nt, f3 nb)
-{
-	const float s_theta = sk_sqrtf(1 - r1 * r1);
-	const float phi = (float) ((2.0 * 3.14159265358979323846) * (double) r2); // (2.0f*M_PI)*r2 in double, narrowed
-	float sn, cs;
-	sincos_spec(phi, sn, cs);
-	const float sx = s_theta * cs, sy = r1, sz = s_theta * sn;
-	return mk3((sx * nb.x + sy * N.x) + sz * nt.x,
-			   (sx * nb.y + sy * N.y) + sz * nb.y,
-			   (sx * nb.z + sy * N.z) + sz * nb.z);
-}
 
 // shade() (raytrace.h:139-227) with the recursion depth as a template
 // parameter: LEVELS == the `depth` argument the reference would carry here.
@@ -181,13 +57,6 @@ SKR_DEV f3 shade(const SceneView &sv, const RenderParams &p, f3 o, f3 d, uint32_
 		total = total / (float) p.num_path_traces;
 		return (direct / (float) 3.14159265358979323846 + total * 2.0f) * ld3(sv.kd[sph]);
 	}
-}
-
-SKR_DEV uint32_t wave_sum(uint32_t v)
-{
-#pragma unroll
-	for(int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-	return v;
 }
 
 } // namespace
@@ -308,7 +177,25 @@ __global__ __launch_bounds__(256) void skr_render_kernel(const RenderParams p)
 
 // ---------------------------------------------------------------- launch ----
 
-size_t skr_render_lds_bytes(const RenderParams &p) { return ((size_t) 4 * p.n_spheres + 2 * p.n_lights) * 16 + 16 * 48; }
+// render_wave.hip
+size_t skr_wave_lds_bytes(const RenderParams &p);
+bool skr_wave_supported(const RenderParams &p);
+hipError_t skr_launch_wave(const RenderParams &p, hipStream_t stream);
+
+// The wave-streaming kernel is the product path wherever it applies (depth <= 3, gillum <= 256);
+// the per-pixel kernel covers the rest (depth 4..6).  SKR_KERNEL=v1 forces the latter (A/B runs).
+static bool use_wave_kernel(const RenderParams &p)
+{
+	const char *e = getenv("SKR_KERNEL");
+	if(e && !strcmp(e, "v1")) return false;
+	return skr_wave_supported(p);
+}
+
+size_t skr_render_lds_bytes(const RenderParams &p)
+{
+	if(use_wave_kernel(p)) return skr_wave_lds_bytes(p);
+	return ((size_t) 4 * p.n_spheres + 2 * p.n_lights) * 16 + 16 * 48;
+}
 
 template <int D>
 static hipError_t launch_depth(const RenderParams &p, dim3 grid, size_t lds, hipStream_t stream)
@@ -319,9 +206,14 @@ static hipError_t launch_depth(const RenderParams &p, dim3 grid, size_t lds, hip
 
 hipError_t skr_launch_render(const RenderParams &p, hipStream_t stream, const char **variant)
 {
+	if(use_wave_kernel(p))
+	{
+		*variant = "wave_streaming_v2";
+		return skr_launch_wave(p, stream);
+	}
 	const dim3 grid((p.width + 15) / 16, (p.out_rows + 15) / 16);
 	const size_t lds = skr_render_lds_bytes(p);
-	*variant = "lane_per_pixel_dfs_v1";
+	*variant = "lane_per_pixel_dfs_v1f";
 	switch(p.max_depth)
 	{
 		case 1: return launch_depth<1>(p, grid, lds, stream);

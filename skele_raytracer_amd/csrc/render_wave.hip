@@ -1,0 +1,567 @@
+// "wave-streaming" megakernel: the whole per-pixel loop of the reference
+// (src/main.cpp:129-182) and the shade() tree under it (src/raytrace.h:139-227)
+// for --depth <= 3, organised for 64-lane waves instead of one recursion per pixel.
+//
+// The --gillum recursion is an N-ary tree whose size varies from 1 ray (sky) to
+// 1 + N + N^2 rays per sample, and only ~1/4 of the rays hit anything that needs
+// shading.  Walking it one pixel per lane leaves ~18 % of the lanes active
+// (profiles/r01_v1_*).  Here every wave owns an 8x8 pixel tile and streams the
+// tree level by level through small LDS queues:
+//
+//   primary rays (1 lane = 1 pixel)
+//     -> parents are compacted into lanes [0,G) a group at a time
+//        -> child rays are dealt round-robin, 64 per round: lane = (parent, child)
+//           misses deposit their contribution in the parent's slot array at once,
+//           sphere hits are pushed (ballot + prefix count) into a ring queue
+//        -> whenever a queue holds a full batch it is drained with one lane per
+//           hit: level-1 hits become the next set of parents (held in registers of
+//           lanes [0,A)), leaf hits are shaded 64 at a time
+//     -> slot arrays are summed per parent strictly in child order, because the
+//        reference accumulates `total += r1*shade()/pdf` sequentially in float
+//        (raytrace.h:117-131) and float addition does not commute with reordering.
+//
+// Arithmetic is the same spec as everywhere else (device_math.h); only the
+// schedule differs, so results are bit-identical to the per-pixel kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "shade_common.h"
+
+namespace {
+
+constexpr int QF = 8;        // dwords per queue record: d.xyz, b, D, packed ids, slot, r1
+constexpr int Q_CAP = 128;   // ring capacity (power of two) >= batch-1 + 64
+constexpr int S0_MAX = 256;  // level-1 contribution slots of one parent group  (G * N <= S0_MAX)
+constexpr int S1_MAX = 512;  // leaf contribution slots of one active batch      (A * N <= S1_MAX)
+constexpr int SLOT_FLOATS = (S0_MAX + S1_MAX) * 3 + 128; // + one pad dword per parent (bank spread)
+constexpr int WAVE_LDS_FLOATS = SLOT_FLOATS + 2 * Q_CAP * QF + 64 /*parent lane table*/ + 64 * 3 /*group results*/ + 48 /*8x8 u8 tile*/;
+
+SKR_DEV void wave_lds_fence()
+{ // producer and consumer lanes are in the same wave: ordering only, no instruction
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
+SKR_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+SKR_DEV f3 shfl3(f3 v, int src) { return mk3(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64)); }
+SKR_DEV int lanes_below(unsigned long long m)
+{
+	return (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+}
+
+struct Queue { // ring of sphere-hit records in LDS, SoA by field; head/count are wave-uniform
+	float *base;
+	int head, count;
+};
+
+struct HitRec {
+	f3 d;          // ray direction
+	float b, D;    // the spec's float quadratic coefficients of the winning sphere
+	uint32_t ids;  // sphere | parent lane << 16 | child index << 24
+	int slot;      // dword offset of the contribution slot in the wave's slot area
+	float r1;
+};
+
+SKR_DEV void q_push(Queue &q, bool pred, const HitRec &h)
+{
+	const unsigned long long m = __ballot(pred);
+	if(pred)
+	{
+		const int e = (q.head + q.count + lanes_below(m)) & (Q_CAP - 1);
+		float *r = q.base + e;
+		r[0 * Q_CAP] = h.d.x;
+		r[1 * Q_CAP] = h.d.y;
+		r[2 * Q_CAP] = h.d.z;
+		r[3 * Q_CAP] = h.b;
+		r[4 * Q_CAP] = h.D;
+		r[5 * Q_CAP] = __uint_as_float(h.ids);
+		r[6 * Q_CAP] = __int_as_float(h.slot);
+		r[7 * Q_CAP] = h.r1;
+	}
+	q.count = uni(q.count + (int) __popcll(m));
+}
+
+SKR_DEV HitRec q_read(const Queue &q, int j)
+{
+	const float *r = q.base + ((q.head + j) & (Q_CAP - 1));
+	HitRec h;
+	h.d = mk3(r[0 * Q_CAP], r[1 * Q_CAP], r[2 * Q_CAP]);
+	h.b = r[3 * Q_CAP];
+	h.D = r[4 * Q_CAP];
+	h.ids = __float_as_uint(r[5 * Q_CAP]);
+	h.slot = __float_as_int(r[6 * Q_CAP]);
+	h.r1 = r[7 * Q_CAP];
+	return h;
+}
+
+SKR_DEV void q_drop(Queue &q, int m)
+{
+	q.head = uni((q.head + m) & (Q_CAP - 1));
+	q.count = uni(q.count - m);
+}
+
+// A tree node whose children are being traced, held in the registers of one lane.
+struct Parent {
+	f3 co;          // child ray origin: P + 0.00001f (raytrace.h:128)
+	f3 N, nt, nb;   // normal and the tangent basis of utils.h:148-165
+	uint32_t pixel; // RNG key: global pixel index
+	uint32_t node;  // RNG key: this node's id (root 0, child c of n = n*N + c + 1)
+};
+
+struct Wave {
+	SceneView sv;
+	const RenderParams *p;
+	float *slots;
+	int lane;
+	int N;            // num_path_traces
+	uint32_t magicN;  // ceil(2^24 / N): t / N == (t * magicN) >> 24 for t < 65536, N <= 256
+	uint32_t aa;
+	float pdf;
+};
+
+// closest accepted sphere without forming the winner's exact t2 (done later, in the
+// compacted shading pass): returns the sphere and its float coefficients b, D.
+SKR_DEV int closest_sphere_deferred(const SceneView &sv, f3 o, f3 d, const RayFilt &f, float &b_out, float &D_out)
+{
+	int best = -1;
+	float best_lo = __builtin_inff(), best_hi = __builtin_inff(), others_lo = __builtin_inff();
+	b_out = 0.0f;
+	D_out = 0.0f;
+	for(int i = 0; i < sv.ns; i++)
+	{
+		float lo, hi, b, D;
+		if(sphere_bracket(o, d, f, sv.geom[i], lo, hi, b, D))
+		{
+			if(hi < best_hi)
+			{
+				others_lo = __builtin_fminf(others_lo, best_lo);
+				best_lo = lo;
+				best_hi = hi;
+				best = i;
+				b_out = b;
+				D_out = D;
+			}
+			else others_lo = __builtin_fminf(others_lo, lo);
+		}
+	}
+	if(best >= 0 && !(others_lo > best_hi))
+	{ // brackets overlap: the exact loop names the winner; recompute its coefficients
+		float tmin;
+		const RayConst r = make_ray(o, d);
+		best = closest_sphere_exact(sv, r, tmin);
+		const f3 e = o - ld3(sv.geom[best]);
+		b_out = 2 * dot3(d, e);
+		const float c = dot3(e, e) - sv.geom[best].w;
+		D_out = b_out * b_out - f.four_a * c;
+	}
+	return best;
+}
+
+// One round of child rays: lane = task task0 + lane = (parent k, child i) of the parents
+// held in lanes [0, np).  The contribution slot of (k, i) is slots[sbase + k*(3N+1) + 3i].
+SKR_DEV void child_round(const Wave &w, const Parent &par, int np, int task0, int sbase, Queue &q, Counters &cn)
+{
+	const int t = task0 + w.lane;
+	const bool valid = t < np * w.N;
+	const int k = valid ? (int) (((uint32_t) t * w.magicN) >> 24) : 0;
+	const int i = t - k * w.N;
+	const f3 co = shfl3(par.co, k), N = shfl3(par.N, k), nt = shfl3(par.nt, k), nb = shfl3(par.nb, k);
+	const uint32_t pixel = (uint32_t) __shfl((int) par.pixel, k, 64), node = (uint32_t) __shfl((int) par.node, k, 64);
+	HitRec h;
+	h.d = mk3(0, 0, 0);
+	h.b = h.D = h.r1 = 0.0f;
+	h.ids = 0;
+	h.slot = sbase + k * (3 * w.N + 1) + 3 * i;
+	bool hit = false;
+	if(valid)
+	{
+		uint32_t rnd[4];
+		philox4x32_10(pixel, w.aa, node, (uint32_t) i >> 1, w.p->seed_lo, w.p->seed_hi, rnd);
+		const float r1 = (i & 1) ? u31_to_unit(rnd[2]) : u31_to_unit(rnd[0]);
+		const float r2 = (i & 1) ? u31_to_unit(rnd[3]) : u31_to_unit(rnd[1]);
+		const f3 d = gi_direction(r1, r2, N, nt, nb);
+		cn.rays++;
+		const RayFilt f = make_filt(d);
+		float b, D;
+		const int sph = closest_sphere_deferred(w.sv, co, d, f, b, D);
+		bool tri = false;
+		if(w.sv.nt > 0)
+		{ // raytrace.h:171-186 needs the sphere's exact t to compare against
+			const float tmin = (sph >= 0) ? near_root_exact(f.two_a, b, D) : __builtin_inff();
+			const RayConst r = RayConst{co, d, f.two_a, f.four_a};
+			tri = any_triangle_closer(w.sv, r, tmin);
+		}
+		if(tri || sph < 0)
+		{ // raytrace.h:189-192 / :221-224, then :130: total += (r1 * colour) / pdf
+			const f3 colour = tri ? mk3(0, 0, 0) : w.p->background;
+			const f3 contrib = (colour * r1) / w.pdf;
+			float *s = w.slots + h.slot;
+			s[0] = contrib.x;
+			s[1] = contrib.y;
+			s[2] = contrib.z;
+		}
+		else
+		{
+			hit = true;
+			h.d = d;
+			h.b = b;
+			h.D = D;
+			h.ids = (uint32_t) sph | ((uint32_t) k << 16) | ((uint32_t) i << 24);
+			h.r1 = r1;
+		}
+	}
+	q_push(q, hit, h);
+}
+
+// Shade m <= 64 queued hits whose node has depth 1 (its own children are shade(depth 0) == 0):
+// raytrace.h:194-213 with indirect = (0,0,0)/N, then the parent's accumulation term (:130).
+SKR_DEV void shade_leaf_batch(const Wave &w, Queue &q, const Parent &par, int m, Counters &cn)
+{
+	wave_lds_fence();
+	const bool act = w.lane < m;
+	HitRec h = q_read(q, act ? w.lane : 0);
+	const int k = (int) ((h.ids >> 16) & 0xffu);
+	const f3 co = shfl3(par.co, act ? k : 0);
+	if(act)
+	{
+		const int sph = (int) (h.ids & 0xffffu);
+		const float two_a = 2 * dot3(h.d, h.d);
+		const float t = near_root_exact(two_a, h.b, h.D);
+		const f3 P = co + h.d * t;
+		const f3 N = normalize3(P - ld3(w.sv.geom[sph]));
+		cn.hits++;
+		const f3 direct = direct_light(w.sv, *w.p, sph, P, N, cn);
+		const f3 total = mk3(0, 0, 0) / (float) w.N;
+		const f3 colour = (direct / (float) 3.14159265358979323846 + total * 2.0f) * ld3(w.sv.kd[sph]);
+		const f3 contrib = (colour * h.r1) / w.pdf;
+		float *s = w.slots + h.slot;
+		s[0] = contrib.x;
+		s[1] = contrib.y;
+		s[2] = contrib.z;
+	}
+	q_drop(q, m);
+	wave_lds_fence();
+}
+
+// Sum the N child contributions of the parent held by this lane, strictly in child order.
+SKR_DEV f3 sum_slots(const Wave &w, int sbase, int k)
+{
+	const float *s = w.slots + sbase + k * (3 * w.N + 1);
+	f3 total = mk3(0, 0, 0);
+	for(int i = 0; i < w.N; i++) total = total + mk3(s[3 * i], s[3 * i + 1], s[3 * i + 2]);
+	return total;
+}
+
+// DEPTH == 3: m <= A queued level-1 hits become the active parents (lanes [0,m)); their
+// N leaf rays each are traced in rounds, leaf hits are shaded in batches of 64, and each
+// parent's result is deposited in ITS parent's slot (raytrace.h:130).
+SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, const Parent &par0, int m, Counters &cn)
+{
+	wave_lds_fence();
+	const bool act = w.lane < m;
+	const HitRec h = q_read(q1, act ? w.lane : 0);
+	const int k0 = (int) ((h.ids >> 16) & 0xffu);
+	const f3 co0 = shfl3(par0.co, act ? k0 : 0);
+	const uint32_t pixel = (uint32_t) __shfl((int) par0.pixel, act ? k0 : 0, 64);
+	q_drop(q1, m);
+	Parent par1;
+	par1.co = par1.N = par1.nt = par1.nb = mk3(0, 0, 0);
+	par1.pixel = pixel;
+	par1.node = ((h.ids >> 24) & 0xffu) + 1u; // child i of the root (node 0): 0*N + i + 1
+	f3 direct1 = mk3(0, 0, 0);
+	int sph1 = 0;
+	if(act)
+	{
+		sph1 = (int) (h.ids & 0xffffu);
+		const float two_a = 2 * dot3(h.d, h.d);
+		const float t = near_root_exact(two_a, h.b, h.D);
+		const f3 P = co0 + h.d * t;
+		par1.N = normalize3(P - ld3(w.sv.geom[sph1]));
+		cn.hits++;
+		direct1 = direct_light(w.sv, *w.p, sph1, P, par1.N, cn);
+		tangent_basis(par1.N, par1.nt, par1.nb);
+		par1.co = add_scalar(P, 0.00001f);
+	}
+	const int sbase1 = S0_MAX * 3 + 64;
+	const int ntasks = m * w.N;
+	for(int task0 = 0; task0 < ntasks; task0 += 64)
+	{
+		child_round(w, par1, m, task0, sbase1, q2, cn);
+		while(q2.count >= 64) shade_leaf_batch(w, q2, par1, 64, cn);
+	}
+	while(q2.count > 0) shade_leaf_batch(w, q2, par1, q2.count < 64 ? q2.count : 64, cn);
+	wave_lds_fence();
+	if(act)
+	{
+		f3 total = sum_slots(w, sbase1, w.lane);
+		total = total / (float) w.N;
+		const f3 colour = (direct1 / (float) 3.14159265358979323846 + total * 2.0f) * ld3(w.sv.kd[sph1]);
+		const f3 contrib = (colour * h.r1) / w.pdf;
+		float *s = w.slots + h.slot;
+		s[0] = contrib.x;
+		s[1] = contrib.y;
+		s[2] = contrib.z;
+	}
+	wave_lds_fence();
+}
+
+// One sample of every pixel of the wave's tile: raytrace.h:139-227 at depth DEPTH.
+template <int DEPTH>
+SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pixel, Queue &q1, Queue &q2, int *lane_tbl, float *gres, Counters &cn)
+{
+	const RenderParams &p = *w.p;
+	// ---- primary rays: one lane per pixel
+	f3 result = mk3(0, 0, 0);
+	bool hit = false;
+	int sph0 = 0;
+	f3 direct0 = mk3(0, 0, 0);
+	Parent mine;
+	mine.co = mine.N = mine.nt = mine.nb = mk3(0, 0, 0);
+	mine.pixel = pixel;
+	mine.node = 0;
+	if(valid)
+	{
+		cn.rays++;
+		const RayConst r = make_ray(o, d);
+		float tmin;
+		const int sph = closest_sphere(w.sv, r, tmin);
+		if(w.sv.nt > 0 && any_triangle_closer(w.sv, r, tmin)) result = mk3(0, 0, 0);
+		else if(sph < 0) result = p.background;
+		else
+		{
+			hit = true;
+			sph0 = sph;
+			cn.hits++;
+			const f3 P = o + d * tmin;
+			mine.N = normalize3(P - ld3(w.sv.geom[sph]));
+			direct0 = direct_light(w.sv, p, sph, P, mine.N, cn);
+			result = direct0;
+			if(DEPTH > 1 && p.monte_carlo)
+			{
+				tangent_basis(mine.N, mine.nt, mine.nb);
+				mine.co = add_scalar(P, 0.00001f);
+			}
+		}
+	}
+	if(!p.monte_carlo) return result;
+
+	f3 indirect = mk3(0, 0, 0); // sum of the children's terms; stays 0 when they are all shade(depth 0)
+	if constexpr(DEPTH > 1)
+	{
+		const unsigned long long M0 = __ballot(hit);
+		const int n0 = (int) __popcll(M0);
+		const int rank = lanes_below(M0);
+		const int G = uni(S0_MAX / (w.N > 0 ? w.N : 1) < 64 ? S0_MAX / (w.N > 0 ? w.N : 1) : 64);
+		const int A = uni(S1_MAX / (w.N > 0 ? w.N : 1) < 64 ? S1_MAX / (w.N > 0 ? w.N : 1) : 64);
+		for(int g0 = 0; g0 < n0 && w.N > 0; g0 += G)
+		{
+			const int gp = uni(n0 - g0 < G ? n0 - g0 : G);
+			const bool in_group = hit && rank >= g0 && rank < g0 + gp;
+			// compact this group's parents into lanes [0, gp)
+			if(in_group) lane_tbl[rank - g0] = w.lane;
+			wave_lds_fence();
+			const int src = (w.lane < gp) ? lane_tbl[w.lane] : 0;
+			Parent par0;
+			par0.co = shfl3(mine.co, src);
+			par0.N = shfl3(mine.N, src);
+			par0.nt = shfl3(mine.nt, src);
+			par0.nb = shfl3(mine.nb, src);
+			par0.pixel = (uint32_t) __shfl((int) mine.pixel, src, 64);
+			par0.node = 0;
+			const int ntasks = gp * w.N;
+			for(int task0 = 0; task0 < ntasks; task0 += 64)
+			{
+				if constexpr(DEPTH == 2)
+				{
+					child_round(w, par0, gp, task0, 0, q2, cn);
+					while(q2.count >= 64) shade_leaf_batch(w, q2, par0, 64, cn);
+				}
+				else
+				{
+					child_round(w, par0, gp, task0, 0, q1, cn);
+					while(q1.count >= A) expand_level1_batch(w, q1, q2, par0, A, cn);
+				}
+			}
+			if constexpr(DEPTH == 2)
+			{
+				while(q2.count > 0) shade_leaf_batch(w, q2, par0, q2.count < 64 ? q2.count : 64, cn);
+			}
+			else
+			{
+				while(q1.count > 0) expand_level1_batch(w, q1, q2, par0, q1.count < A ? q1.count : A, cn);
+			}
+			wave_lds_fence();
+			if(w.lane < gp)
+			{
+				const f3 total = sum_slots(w, 0, w.lane);
+				gres[3 * w.lane] = total.x;
+				gres[3 * w.lane + 1] = total.y;
+				gres[3 * w.lane + 2] = total.z;
+			}
+			wave_lds_fence();
+			if(in_group) indirect = mk3(gres[3 * (rank - g0)], gres[3 * (rank - g0) + 1], gres[3 * (rank - g0) + 2]);
+			wave_lds_fence();
+		}
+	}
+	if(hit)
+	{ // raytrace.h:133 + :213
+		const f3 total = indirect / (float) w.N;
+		result = (direct0 / (float) 3.14159265358979323846 + total * 2.0f) * ld3(w.sv.kd[sph0]);
+	}
+	return result;
+}
+
+} // namespace
+
+// One workgroup = 4 independent waves; wave w of block (bx, by) owns the 8x8 pixel tile
+// (2*bx + (w&1), 2*by + (w>>1)).  Dynamic LDS: scene SoA (shared, staged once) | 4 wave areas.
+template <int DEPTH>
+__global__ __launch_bounds__(256, 2) void skr_wave_kernel(const RenderParams p)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
+	const int ns = p.n_spheres, nl = p.n_lights;
+	float4 *s_geom = lds4, *s_amb = lds4 + ns, *s_kd = lds4 + 2 * ns, *s_ks = lds4 + 3 * ns, *s_lights = lds4 + 4 * ns;
+	const int tid = threadIdx.x;
+	for(int i = tid; i < ns; i += 256)
+	{
+		s_geom[i] = p.sph_geom[i];
+		s_amb[i] = p.sph_amb[i];
+		s_kd[i] = p.sph_kd[i];
+		s_ks[i] = p.sph_ks[i];
+	}
+	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
+	__syncthreads(); // the only workgroup barrier: from here on the four waves never meet again
+
+	const int wave = tid >> 6, lane = tid & 63;
+	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 2 * nl) + wave * WAVE_LDS_FLOATS;
+	Wave w;
+	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl};
+	w.p = &p;
+	w.slots = wbase;
+	w.lane = lane;
+	w.N = p.num_path_traces;
+	w.magicN = (uint32_t) (((1u << 24) + (uint32_t) (w.N > 0 ? w.N : 1) - 1u) / (uint32_t) (w.N > 0 ? w.N : 1));
+	w.aa = 0;
+	w.pdf = (float) (1 / 3.14159265358979323846);
+	Queue q1{wbase + SLOT_FLOATS, 0, 0}, q2{wbase + SLOT_FLOATS + Q_CAP * QF, 0, 0};
+	int *lane_tbl = reinterpret_cast<int *>(wbase + SLOT_FLOATS + 2 * Q_CAP * QF);
+	float *gres = wbase + SLOT_FLOATS + 2 * Q_CAP * QF + 64;
+	unsigned char *s_tile = reinterpret_cast<unsigned char *>(gres + 64 * 3);
+
+	const int lx = lane & 7, ly = lane >> 3;
+	const int x0 = (blockIdx.x * 2 + (wave & 1)) * 8;
+	const uint32_t orow0 = (blockIdx.y * 2 + (wave >> 1)) * 8;
+	const int x = x0 + lx;
+	const uint32_t orow = orow0 + ly;
+	const uint32_t k = orow / p.tile_rows;
+	const uint32_t y = (p.first_tile + k * p.tile_stride) * p.tile_rows + (orow - k * p.tile_rows);
+	const bool valid = x < p.width && orow < p.out_rows && y < (uint32_t) p.height;
+	const uint32_t pixel = y * (uint32_t) p.width + (uint32_t) x;
+
+	Counters cn{0, 0, 0};
+	f3 px = mk3(0, 0, 0);
+	if(p.grid_size > 0)
+	{ // main.cpp:140-166
+		const int ns2 = p.grid_size * p.grid_size;
+		for(int s = 0; s < ns2; s++)
+		{
+			w.aa = (uint32_t) s;
+			uint32_t rnd[4];
+			philox4x32_10(pixel, (uint32_t) s, 0u, 0xFFFFFFFFu, p.seed_lo, p.seed_hi, rnd);
+			const float r = u31_to_unit(rnd[0]);
+			const float u = ((2 * (((float) x + r) * p.inv_width) - 1) * p.angle) * p.aspect;
+			const float v = (1 - 2 * (((float) (int) y + r) * p.inv_height)) * p.angle;
+			const f3 dir = (p.cam_dir + p.cam_right * u) + p.cam_up * v;
+			px = px + shade_tile_sample<DEPTH>(w, valid, p.cam_pos, dir, pixel, q1, q2, lane_tbl, gres, cn);
+		}
+		px = px / (float) ns2;
+	}
+	else
+	{ // main.cpp:168-182
+		const float u = (float) (((2 * (((double) x + 0.5) * (double) p.inv_width) - 1) * (double) p.angle) * (double) p.aspect);
+		const float v = (float) ((1 - 2 * (((double) (int) y + 0.5) * (double) p.inv_height)) * (double) p.angle);
+		const f3 dir = (p.cam_dir + p.cam_right * u) + p.cam_up * v;
+		px = shade_tile_sample<DEPTH>(w, valid, p.cam_pos, dir, pixel, q1, q2, lane_tbl, gres, cn);
+	}
+
+	if(valid && p.rgbf)
+	{
+		float *o = p.rgbf + ((size_t) orow * p.width + x) * 3;
+		o[0] = px.x;
+		o[1] = px.y;
+		o[2] = px.z;
+	}
+	if(p.rgb)
+	{ // pack to u8 in LDS, then store the tile's 8 rows x 24 bytes as 48 dwords
+		unsigned char *t = s_tile + (ly * 8 + lx) * 3;
+		t[0] = (unsigned char) quantise(px.x);
+		t[1] = (unsigned char) quantise(px.y);
+		t[2] = (unsigned char) quantise(px.z);
+		wave_lds_fence();
+		const bool full = (x0 + 8 <= p.width) && ((p.width & 3) == 0);
+		if(full)
+		{
+			if(lane < 48)
+			{
+				const int row = lane / 6, j = lane - row * 6;
+				const uint32_t orow2 = orow0 + row;
+				const uint32_t k2 = orow2 / p.tile_rows;
+				const uint32_t y2 = (p.first_tile + k2 * p.tile_stride) * p.tile_rows + (orow2 - k2 * p.tile_rows);
+				if(orow2 < p.out_rows && y2 < (uint32_t) p.height)
+				{
+					uint32_t *dst = reinterpret_cast<uint32_t *>(p.rgb + ((size_t) orow2 * p.width + x0) * 3);
+					dst[j] = reinterpret_cast<const uint32_t *>(s_tile + row * 24)[j];
+				}
+			}
+		}
+		else if(valid)
+		{
+			unsigned char *dst = p.rgb + ((size_t) orow * p.width + x) * 3;
+			dst[0] = t[0];
+			dst[1] = t[1];
+			dst[2] = t[2];
+		}
+	}
+	if(p.counters)
+	{
+		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays);
+		if(lane == 0)
+		{
+			atomicAdd(&p.counters[0], (unsigned long long) a);
+			atomicAdd(&p.counters[1], (unsigned long long) b);
+			atomicAdd(&p.counters[2], (unsigned long long) c);
+		}
+	}
+}
+
+size_t skr_wave_lds_bytes(const RenderParams &p) { return ((size_t) 4 * p.n_spheres + 2 * p.n_lights) * 16 + (size_t) 4 * WAVE_LDS_FLOATS * 4; }
+
+// The streaming kernel covers --depth 1..3, gillum <= 256, <= 65535 spheres.
+bool skr_wave_supported(const RenderParams &p)
+{
+	return p.max_depth >= 1 && p.max_depth <= 3 && p.num_path_traces <= S0_MAX && p.n_spheres < 65536;
+}
+
+template <int D>
+static hipError_t launch_wave_depth(const RenderParams &p, dim3 grid, size_t lds, hipStream_t stream)
+{
+	// > 64 KiB of dynamic LDS per workgroup has to be opted into
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(skr_wave_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+	if(e != hipSuccess) return e;
+	hipLaunchKernelGGL(skr_wave_kernel<D>, grid, dim3(256), lds, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t skr_launch_wave(const RenderParams &p, hipStream_t stream)
+{
+	const dim3 grid((p.width + 15) / 16, (p.out_rows + 15) / 16);
+	const size_t lds = skr_wave_lds_bytes(p);
+	switch(p.max_depth)
+	{
+		case 1: return launch_wave_depth<1>(p, grid, lds, stream);
+		case 2: return launch_wave_depth<2>(p, grid, lds, stream);
+		case 3: return launch_wave_depth<3>(p, grid, lds, stream);
+		default: return hipErrorInvalidValue;
+	}
+}

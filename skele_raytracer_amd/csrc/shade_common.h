@@ -1,0 +1,184 @@
+// Device functions shared by the render kernels: scene view, traversal,
+// shading (reference src/raytrace.h, blinn_phong.h, utils.h restated for gfx950).
+#pragma once
+
+#include "device_math.h"
+#include "render_params.h"
+
+namespace {
+
+
+// Scene as the kernel sees it: pointers into LDS (spheres, materials, lights)
+// and HBM (triangles, read with wave-uniform addresses).
+struct SceneView {
+	const float4 *geom; // LDS  centre.xyz, r*r
+	const float4 *amb;  // LDS  La*ka, .w = phong power
+	const float4 *kd;   // LDS
+	const float4 *ks;   // LDS
+	const float4 *lights; // LDS [2i] position [2i+1] colour
+	const float4 *tris; // HBM  [3i] v0 [3i+1] e1 [3i+2] e2
+	int ns, nt, nl;
+};
+
+struct Counters {
+	uint32_t rays, hits, shadow_rays;
+};
+
+struct RayConst { // per-ray invariants of utils.h:113-121
+	f3 o, d;
+	float two_a, four_a;
+};
+
+SKR_DEV RayConst make_ray(f3 o, f3 d)
+{
+	const float a = dot3(d, d);
+	return RayConst{o, d, 2 * a, 4 * a};
+}
+
+// raytrace.h:152-165: closest accepted sphere (strict <, first index wins ties),
+// evaluated exactly as written: the binary64 root for every sphere with D >= 0.
+SKR_DEV int closest_sphere_exact(const SceneView &sv, const RayConst &r, float &tmin)
+{
+	int best = -1;
+	tmin = __builtin_inff();
+	for(int i = 0; i < sv.ns; i++)
+	{
+		const float t = sphere_distance(r.o, r.d, r.two_a, r.four_a, sv.geom[i]);
+		if(accept_distance(t) && t < tmin)
+		{
+			tmin = t;
+			best = i;
+		}
+	}
+	return best;
+}
+
+// Same result through the binary32 brackets of device_math.h: the winner is
+// known as soon as its bracket lies strictly below every other accepted
+// sphere's; its exact t2 is then formed once.  Overlapping brackets (two
+// surfaces within ~1e-6 relative of each other along the ray) fall back to the
+// exact loop for that lane.
+SKR_DEV int closest_sphere(const SceneView &sv, const RayConst &r, float &tmin)
+{
+	const RayFilt f = make_filt(r.d);
+	int best = -1;
+	float best_lo = __builtin_inff(), best_hi = __builtin_inff(), others_lo = __builtin_inff();
+	float best_b = 0.0f, best_D = 0.0f;
+	for(int i = 0; i < sv.ns; i++)
+	{
+		float lo, hi, b, D;
+		if(sphere_bracket(r.o, r.d, f, sv.geom[i], lo, hi, b, D))
+		{
+			if(hi < best_hi)
+			{
+				others_lo = __builtin_fminf(others_lo, best_lo);
+				best_lo = lo;
+				best_hi = hi;
+				best = i;
+				best_b = b;
+				best_D = D;
+			}
+			else others_lo = __builtin_fminf(others_lo, lo);
+		}
+	}
+	tmin = __builtin_inff();
+	if(best >= 0)
+	{
+		if(others_lo > best_hi) tmin = (best_lo == best_hi) ? best_lo : near_root_exact(f.two_a, best_b, best_D);
+		else best = closest_sphere_exact(sv, r, tmin);
+	}
+	return best;
+}
+
+// raytrace.h:171-186.  The outcome is binary: once a triangle passes with
+// t < min_distance the sample is black (:221-224) whatever comes later, so a
+// lane stops testing at its first accepted triangle and the wave leaves the
+// loop when every active lane has.
+SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float tmin)
+{
+	bool hit = false;
+	for(int i = 0; i < sv.nt; i++)
+	{
+		const f3 v0 = ld3(sv.tris[3 * i]), e1 = ld3(sv.tris[3 * i + 1]), e2 = ld3(sv.tris[3 * i + 2]);
+		float t;
+		if(!hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
+		if((i & 7) == 7 && __all(hit)) break;
+	}
+	return hit;
+}
+
+// utils.h:42-58: any sphere with 1 < t < inf along the (unbounded) shadow ray.
+SKR_DEV bool occluded(const SceneView &sv, f3 P, f3 L)
+{
+	const f3 o = add_scalar(P, 0.000001f);
+	const RayFilt f = make_filt(L);
+	bool occ = false;
+	for(int i = 0; i < sv.ns; i++)
+	{
+		float lo, hi, b, D;
+		if(!occ) occ = sphere_bracket(o, L, f, sv.geom[i], lo, hi, b, D);
+		if(__all(occ)) break;
+	}
+	return occ;
+}
+
+// raytrace.h:36-44 = bp::ambient (blinn_phong.h:13) + diffuse (:47) + specular (:90).
+// The reference casts the same shadow ray in diffuse and again in specular; one cast serves both.
+SKR_DEV f3 direct_light(const SceneView &sv, const RenderParams &p, int sph, f3 P, f3 N, Counters &cn)
+{
+	const f3 kd = ld3(sv.kd[sph]), ks = ld3(sv.ks[sph]);
+	const float4 ambp = sv.amb[sph];
+	f3 diffuse = mk3(0, 0, 0), specular = mk3(0, 0, 0);
+	const f3 view = normalize3(p.cam_pos - P); // always the camera (blinn_phong.h:93)
+	for(int i = 0; i < sv.nl; i++)
+	{
+		const f3 lp = ld3(sv.lights[2 * i]), lc = ld3(sv.lights[2 * i + 1]);
+		const f3 to_l = lp - P;
+		const float sq = sqr3(to_l);
+		const float len = sk_sqrtf(sq);
+		const f3 L = to_l * sk_divf(1.0f, len);
+		bool lit = true;
+		if(p.use_shadows)
+		{
+			cn.shadow_rays++;
+			lit = !occluded(sv, P, L);
+		}
+		if(lit)
+		{
+			const float intensity = sk_divf(1.0f, len * len); // 1/powf(|d|,2) == 1/(d*d)
+			diffuse = diffuse + ((kd * lc) * intensity) * max0(dot3(N, L));
+			const f3 vl = view + L;
+			const f3 H = vl / length3(vl);
+			specular = specular + ((ks * lc) * intensity) * powf_spec(max0(dot3(N, H)), ambp.w);
+		}
+	}
+	f3 total = mk3(0, 0, 0);
+	total = total + ld3(ambp);
+	total = total + diffuse;
+	total = total + specular;
+	return total;
+}
+
+// raytrace.h:22-30 + :117-125: hemisphere sample and the reference's basis mix
+// (perp_to_both.y/.z where perp_to_normal.y/.z belongs — kept).
+SKR_DEV f3 gi_direction(float r1, float r2, f3 N, f3 nt, f3 nb)
+{
+	const float s_theta = sk_sqrtf(1 - r1 * r1);
+	const float phi = (float) ((2.0 * 3.14159265358979323846) * (double) r2); // (2.0f*M_PI)*r2 in double, narrowed
+	float sn, cs;
+	sincos_spec(phi, sn, cs);
+	const float sx = s_theta * cs, sy = r1, sz = s_theta * sn;
+	return mk3((sx * nb.x + sy * N.x) + sz * nt.x,
+			   (sx * nb.y + sy * N.y) + sz * nb.y,
+			   (sx * nb.z + sy * N.z) + sz * nb.z);
+}
+
+SKR_DEV uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+	for(int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+	return v;
+}
+
+
+} // namespace
