@@ -34,23 +34,24 @@ VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
 
 def cpu_baseline():
     """The oracle (CPU restatement, counter RNG, OpenMP over (row, 32-pixel span) items) timed on this
-    box's host cores on a bounded, representative sample of the same frame: every 4th 8-row tile."""
+    box's host cores on the same workload: whole frames, repeated until >= 8 s of wall time."""
     from oracle import pyoracle as orc
     cores = orc.host_cores()
     scene = orc.OracleScene(SCENE)
-    rays = 0
-    rows = 0
+    kw = dict(rng=orc.RNG_COUNTER, math=orc.MATH_SHARED, threads=cores, gillum=KW["gillum"], shadow=KW["shadow"],
+              depth=KW["depth"], seed=KW["seed"])
+    orc.render(scene, W, H, y0=0, y1=64, **kw)  # warm up the thread pool
+    rays, frames = 0, 0
     t0 = time.perf_counter()
-    for t in range(0, (H + TILE_ROWS - 1) // TILE_ROWS, 4):
-        y0, y1 = t * TILE_ROWS, min(H, (t + 1) * TILE_ROWS)
-        _, _, st = orc.render(scene, W, H, rng=orc.RNG_COUNTER, math=orc.MATH_SHARED, y0=y0, y1=y1, threads=cores,
-                              gillum=KW["gillum"], shadow=KW["shadow"], depth=KW["depth"], seed=KW["seed"])
+    while frames < 2 or time.perf_counter() - t0 < 8.0:
+        _, _, st = orc.render(scene, W, H, **kw)
         rays += int(st[0])
-        rows += y1 - y0
+        frames += 1
     dt = time.perf_counter() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "oracle/liboracle.so (C restatement, -O2, OpenMP %d threads = cgroup CPU quota), every 4th %d-row tile of the same "
-                      "frame: %d rows, %d radiance rays in %.2f s" % (cores, TILE_ROWS, rows, rays, dt)}
+            "ms_per_frame": dt / frames * 1e3,
+            "sample": "oracle/liboracle.so (C restatement of the reference path, gcc -O2, OpenMP %d threads = this box's cgroup CPU "
+                      "quota), %d whole frames of the same workload: %d radiance rays in %.2f s" % (cores, frames, rays, dt)}
 
 
 def main():
@@ -79,29 +80,27 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
+    from skele_raytracer_amd.distributed import FrameSharder
+
     scene = skr.parse_scene(SCENE)
     r = skr.Renderer(scene, local_rank)
     opt = skr.Options(W, H, **KW)
-    n_tiles_total = (H + TILE_ROWS - 1) // TILE_ROWS
-    k_max = (n_tiles_total + world - 1) // world            # equal-size (padded) tile buffers on every rank
-    mine = torch.zeros((k_max * TILE_ROWS, W, 3), dtype=torch.uint8, device=dev)
-    gathered = [torch.zeros_like(mine) for _ in range(world)] if (world > 1 and rank == 0) else None
-    frame = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
+    sharder = FrameSharder(W, H, TILE_ROWS, rank, world, dev)  # interleaved row tiles + one RCCL all-gather
+    k_max = sharder.k_max
     stream = torch.cuda.current_stream(dev)
+    ev_box = [None]
 
-    def step(ev=None):
+    def render_into(buf):
+        ev = ev_box[0]
         if ev:
             ev[0].record(stream)
-        r.render_tiles_into(opt, TILE_ROWS, rank, world, mine.data_ptr(), None, stream.cuda_stream)
+        r.render_tiles_into(opt, TILE_ROWS, rank, world, buf.data_ptr(), None, stream.cuda_stream)
         if ev:
             ev[1].record(stream)
-        if world > 1:
-            dist.gather(mine, gathered, dst=0)
-            if rank == 0:  # de-interleave: tile t lives at rank t % G, slot t // G
-                g = torch.stack(gathered).view(world, k_max, TILE_ROWS, W, 3).permute(1, 0, 2, 3, 4).reshape(-1, W, 3)
-                frame.copy_(g[:H])
-        else:
-            frame.copy_(mine[:H])
+
+    def step(ev=None):
+        ev_box[0] = ev
+        sharder.step(render_into)
 
     def sync():
         if world > 1:
@@ -154,11 +153,11 @@ def main():
                        "rays_per_frame": rays_per_frame, "nominal_rays": skr.radiance_ray_count(opt),
                        "nominal_mrays_per_s": skr.radiance_ray_count(opt) * args.steps / dt / 1e6,
                        "shadow_rays_per_frame": shadow / args.steps, "partition": "interleaved %d-row tiles, rank = tile %% %d" % (TILE_ROWS, world),
-                       "gather": "RCCL gather of u8 tiles to rank 0" if world > 1 else "none (1 GPU)",
+                       "gather": "RCCL all-gather of the u8 tile buffers, rank 0 de-interleaves" if world > 1 else "none (1 GPU)",
                        "kernel": r.kernel_variant(), "seed": KW["seed"]},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "skr_render_kernel<3>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": launch_bytes,
+                         "kernel": "skr_wave_kernel<3>" if r.kernel_variant().startswith("wave") else "skr_render_kernel<3>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": launch_bytes,
                          "note": "compulsory HBM traffic is the u8 framebuffer + ~1 KB of scene: this path is FP32-VALU bound, see roofline_valu"},
             "roofline_valu": {"bound": "fp32_valu", "achieved": alg_flop / (kernel_ms * 1e-3) / 1e12 / world * 1.0,
                               "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": alg_flop / (kernel_ms * 1e-3) / 1e12 / world / VALU_PEAK_TFLOPS,

@@ -91,8 +91,8 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	if(nt3) memcpy(&blob[r->off_tris], scene->tris.data(), nt3 * 16);
 	hipError_t e = hipMalloc((void **) &r->d_blob, blob.size() * 16);
 	if(e == hipSuccess) e = hipMemcpy(r->d_blob, blob.data(), blob.size() * 16, hipMemcpyHostToDevice);
-	if(e == hipSuccess) e = hipMalloc((void **) &r->d_counters, 8 * sizeof(unsigned long long));
-	if(e == hipSuccess) e = hipMemset(r->d_counters, 0, 8 * sizeof(unsigned long long));
+	if(e == hipSuccess) e = hipMalloc((void **) &r->d_counters, SKR_COUNTER_SHARDS * 4 * sizeof(unsigned long long));
+	if(e == hipSuccess) e = hipMemset(r->d_counters, 0, SKR_COUNTER_SHARDS * 4 * sizeof(unsigned long long));
 	if(e != hipSuccess)
 	{
 		skr_set_error("scene upload failed: %s", hipGetErrorString(e));
@@ -247,10 +247,12 @@ int skr_renderer_read_counters(skr_renderer *r, uint64_t out[3], int reset)
 {
 	if(!r || !out) return SKR_ERR_ARG;
 	SKR_HIP(hipSetDevice(r->device));
-	unsigned long long h[3];
-	SKR_HIP(hipMemcpy(h, r->d_counters, sizeof h, hipMemcpyDeviceToHost)); // synchronises with prior launches
-	for(int k = 0; k < 3; k++) out[k] = h[k];
-	if(reset) SKR_HIP(hipMemset(r->d_counters, 0, 8 * sizeof(unsigned long long)));
+	std::vector<unsigned long long> h((size_t) SKR_COUNTER_SHARDS * 4);
+	SKR_HIP(hipMemcpy(h.data(), r->d_counters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost)); // synchronises with prior launches
+	out[0] = out[1] = out[2] = 0;
+	for(size_t s = 0; s < SKR_COUNTER_SHARDS; s++)
+		for(int k = 0; k < 3; k++) out[k] += h[4 * s + k];
+	if(reset) SKR_HIP(hipMemset(r->d_counters, 0, h.size() * sizeof(unsigned long long)));
 	return SKR_OK;
 }
 

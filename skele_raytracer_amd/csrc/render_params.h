@@ -8,6 +8,8 @@ struct f3 {
 	float x, y, z;
 };
 
+#define SKR_COUNTER_SHARDS 4096u
+
 struct RenderParams {
 	// image and partition (include/skr.h skr_render_tiles)
 	int32_t width, height;
@@ -25,5 +27,5 @@ struct RenderParams {
 	// outputs (device)
 	uint8_t *rgb;
 	float *rgbf;
-	unsigned long long *counters; // [0] radiance rays [1] sphere hits shaded [2] shadow rays
+	unsigned long long *counters; // SKR_COUNTER_SHARDS x {radiance rays, sphere hits shaded, shadow rays, pad}
 };

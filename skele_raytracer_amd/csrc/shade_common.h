@@ -11,7 +11,7 @@ namespace {
 // Scene as the kernel sees it: pointers into LDS (spheres, materials, lights)
 // and HBM (triangles, read with wave-uniform addresses).
 struct SceneView {
-	const float4 *geom; // LDS  centre.xyz, r*r
+	const float4 *geom; // LDS  centre.xyz, r*r; ns + 1 entries (the last is a pad for the loops' prefetch)
 	const float4 *amb;  // LDS  La*ka, .w = phong power
 	const float4 *kd;   // LDS
 	const float4 *ks;   // LDS
@@ -41,9 +41,12 @@ SKR_DEV int closest_sphere_exact(const SceneView &sv, const RayConst &r, float &
 {
 	int best = -1;
 	tmin = __builtin_inff();
+	float4 g_next = sv.geom[0];
 	for(int i = 0; i < sv.ns; i++)
 	{
-		const float t = sphere_distance(r.o, r.d, r.two_a, r.four_a, sv.geom[i]);
+		const float4 g = g_next;
+		g_next = sv.geom[i + 1]; // software prefetch; geom[] carries one pad entry
+		const float t = sphere_distance(r.o, r.d, r.two_a, r.four_a, g);
 		if(accept_distance(t) && t < tmin)
 		{
 			tmin = t;
@@ -64,10 +67,13 @@ SKR_DEV int closest_sphere(const SceneView &sv, const RayConst &r, float &tmin)
 	int best = -1;
 	float best_lo = __builtin_inff(), best_hi = __builtin_inff(), others_lo = __builtin_inff();
 	float best_b = 0.0f, best_D = 0.0f;
+	float4 g_next = sv.geom[0];
 	for(int i = 0; i < sv.ns; i++)
 	{
+		const float4 g = g_next;
+		g_next = sv.geom[i + 1];
 		float lo, hi, b, D;
-		if(sphere_bracket(r.o, r.d, f, sv.geom[i], lo, hi, b, D))
+		if(sphere_bracket(r.o, r.d, f, g, lo, hi, b, D))
 		{
 			if(hi < best_hi)
 			{
@@ -113,10 +119,13 @@ SKR_DEV bool occluded(const SceneView &sv, f3 P, f3 L)
 	const f3 o = add_scalar(P, 0.000001f);
 	const RayFilt f = make_filt(L);
 	bool occ = false;
+	float4 g_next = sv.geom[0];
 	for(int i = 0; i < sv.ns; i++)
 	{
+		const float4 g = g_next;
+		g_next = sv.geom[i + 1];
 		float lo, hi, b, D;
-		if(!occ) occ = sphere_bracket(o, L, f, sv.geom[i], lo, hi, b, D);
+		if(!occ) occ = sphere_bracket(o, L, f, g, lo, hi, b, D);
 		if(__all(occ)) break;
 	}
 	return occ;

@@ -1,0 +1,71 @@
+"""world_size-2/3 `gloo` tests of the multi-GPU path on CPU: partition arithmetic, the one
+collective and the de-interleave.  The per-rank renderer is stood in for by the oracle (tests may
+use it); on the GPU box bench.py plugs the HIP renderer into the same FrameSharder."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import scene_path
+from skele_raytracer_amd import distributed as D
+
+W, H, TILE = 96, 53, 8
+KW = dict(gillum=3, shadow=True, seed=4)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as orc
+    scene = orc.OracleScene(scene_path("spheres2.scn"))
+    sh = D.FrameSharder(W, H, TILE, rank, world, torch.device("cpu"))
+
+    def render_into(buf):
+        buf.zero_()
+        for k, t in enumerate(D.my_tiles(H, TILE, rank, world)):
+            y0, y1 = t * TILE, min(H, (t + 1) * TILE)
+            rgb, _, _ = orc.render(scene, W, H, y0=y0, y1=y1, threads=1, **KW)
+            buf[k * TILE:k * TILE + (y1 - y0)] = torch.from_numpy(rgb)
+
+    frame = sh.step(render_into)
+    if rank == 0:
+        np.save(out_path, frame.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_frame_equals_single_process_frame(tmp_path, oracle, world):
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    want, _, _ = oracle.render(scene_path("spheres2.scn"), W, H, **KW)
+    assert got.shape == (H, W, 3) and np.array_equal(got, want)
+
+
+def test_partition_arithmetic():
+    assert D.tiles_total(1080, 8) == 135 and D.tiles_per_rank(1080, 8, 8) == 17
+    assert D.my_tiles(20, 8, 1, 2) == [1] and D.my_tiles(20, 8, 0, 2) == [0, 2]
+    for h, tile, world in [(1080, 8, 8), (53, 8, 3), (7, 16, 4), (2160, 16, 8)]:
+        seen = sorted(t for r in range(world) for t in D.my_tiles(h, tile, r, world))
+        assert seen == list(range(D.tiles_total(h, tile)))
+        k_max = D.tiles_per_rank(h, tile, world)
+        g = torch.zeros((world, k_max * tile, 4, 3), dtype=torch.uint8)
+        for r in range(world):
+            for k, t in enumerate(D.my_tiles(h, tile, r, world)):
+                g[r, k * tile:(k + 1) * tile] = t % 251
+        f = D.deinterleave(g, h, tile, world)
+        assert f.shape[0] == h
+        assert all(int(f[y, 0, 0]) == (y // tile) % 251 for y in range(h))
