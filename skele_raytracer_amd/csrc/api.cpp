@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -91,8 +92,8 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	if(nt3) memcpy(&blob[r->off_tris], scene->tris.data(), nt3 * 16);
 	hipError_t e = hipMalloc((void **) &r->d_blob, blob.size() * 16);
 	if(e == hipSuccess) e = hipMemcpy(r->d_blob, blob.data(), blob.size() * 16, hipMemcpyHostToDevice);
-	if(e == hipSuccess) e = hipMalloc((void **) &r->d_counters, SKR_COUNTER_SHARDS * 4 * sizeof(unsigned long long));
-	if(e == hipSuccess) e = hipMemset(r->d_counters, 0, SKR_COUNTER_SHARDS * 4 * sizeof(unsigned long long));
+	if(e == hipSuccess) e = hipMalloc((void **) &r->d_counters, (SKR_COUNTER_SHARDS * 4 + 8) * sizeof(unsigned long long));
+	if(e == hipSuccess) e = hipMemset(r->d_counters, 0, (SKR_COUNTER_SHARDS * 4 + 8) * sizeof(unsigned long long));
 	if(e != hipSuccess)
 	{
 		skr_set_error("scene upload failed: %s", hipGetErrorString(e));
@@ -247,11 +248,15 @@ int skr_renderer_read_counters(skr_renderer *r, uint64_t out[3], int reset)
 {
 	if(!r || !out) return SKR_ERR_ARG;
 	SKR_HIP(hipSetDevice(r->device));
-	std::vector<unsigned long long> h((size_t) SKR_COUNTER_SHARDS * 4);
+	std::vector<unsigned long long> h((size_t) SKR_COUNTER_SHARDS * 4 + 8);
 	SKR_HIP(hipMemcpy(h.data(), r->d_counters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost)); // synchronises with prior launches
 	out[0] = out[1] = out[2] = 0;
 	for(size_t s = 0; s < SKR_COUNTER_SHARDS; s++)
 		for(int k = 0; k < 3; k++) out[k] += h[4 * s + k];
+	if(getenv("SKR_PRINT_STAMPS"))
+	{ // diagnostic builds (-DSKR_STAMPS=1) only: per-phase cycle sums
+		for(int k = 0; k < 8; k++) fprintf(stderr, "stamp[%d] = %llu\n", k, h[(size_t) SKR_COUNTER_SHARDS * 4 + k]);
+	}
 	if(reset) SKR_HIP(hipMemset(r->d_counters, 0, h.size() * sizeof(unsigned long long)));
 	return SKR_OK;
 }

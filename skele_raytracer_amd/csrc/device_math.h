@@ -219,11 +219,11 @@ SKR_DEV RayFilt make_filt(f3 d)
 // One sphere against one ray.  Returns false for a certain miss.  Otherwise
 // [lo, hi] brackets t2 (lo == hi when it had to be resolved exactly) and b, D
 // are the spec's float coefficients (kept for the exact evaluation of the winner).
-SKR_DEV bool sphere_bracket(f3 o, f3 d, const RayFilt &f, float4 sph, float &lo, float &hi, float &b, float &D)
+// Rays that share an origin (the N children of one node, raytrace.h:128; the shadow rays of one
+// hit point, utils.h:45) share e = o - C and c = e.e - r^2 of utils.h:115-118: formed once per sphere.
+SKR_DEV bool bracket_from_ec(f3 e, float c, f3 d, const RayFilt &f, float &lo, float &hi, float &b, float &D)
 {
-	const f3 e = o - ld3(sph);
 	b = 2 * dot3(d, e);
-	const float c = dot3(e, e) - sph.w;
 	D = b * b - f.four_a * c;
 	// b >= 0 => -b - sqrt(D) <= 0 => t2 <= 0 (or NaN): never accepted.  D < 0 / NaN: miss.
 	if(!(D >= 0.0f) || !(b < 0.0f)) return false;
@@ -246,6 +246,12 @@ SKR_DEV bool sphere_bracket(f3 o, f3 d, const RayFilt &f, float4 sph, float &lo,
 	return true;
 }
 
+SKR_DEV bool sphere_bracket(f3 o, f3 d, const RayFilt &f, float4 sph, float &lo, float &hi, float &b, float &D)
+{
+	const f3 e = o - ld3(sph);
+	const float c = dot3(e, e) - sph.w;
+	return bracket_from_ec(e, c, d, f, lo, hi, b, D);
+}
 
 // utils.h:181-213 with the edges e1 = v1-v0, e2 = v2-v0 precomputed on the host
 // (same subtractions).  u carries the reference's flipped sign; no t>0 test.

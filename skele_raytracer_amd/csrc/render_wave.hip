@@ -29,12 +29,40 @@
 
 namespace {
 
+#ifndef SKR_WAVE_OCC
+#define SKR_WAVE_OCC 3       // waves per SIMD the LDS/VGPR budget below is sized for
+#endif
 constexpr int QF = 8;        // dwords per queue record: d.xyz, b, D, packed ids, slot, r1
-constexpr int Q_CAP = 128;   // ring capacity (power of two) >= batch-1 + 64
-constexpr int S0_MAX = 256;  // level-1 contribution slots of one parent group  (G * N <= S0_MAX)
-constexpr int S1_MAX = 512;  // leaf contribution slots of one active batch      (A * N <= S1_MAX)
-constexpr int SLOT_FLOATS = (S0_MAX + S1_MAX) * 3 + 128; // + one pad dword per parent (bank spread)
-constexpr int WAVE_LDS_FLOATS = SLOT_FLOATS + 2 * Q_CAP * QF + 64 /*parent lane table*/ + 64 * 3 /*group results*/ + 48 /*8x8 u8 tile*/;
+#if SKR_WAVE_OCC >= 3
+constexpr int S0_MAX = 128;  // level-1 contribution slots of one parent group  (G * N <= S0_MAX)
+constexpr int S1_MAX = 256;  // leaf contribution slots of one active batch      (A * N <= S1_MAX)
+#else
+constexpr int S0_MAX = 256;
+constexpr int S1_MAX = 512;
+#endif
+constexpr int PAR_MAX = 32;  // parents per group / per leaf-slot window (G, AW <= PAR_MAX)
+constexpr int Q1_CAP = 128;  // level-1 hits waiting to become parents: <= 63 + 64 entries
+constexpr int Q2_CAP = 128;  // leaf hits waiting to be shaded: <= 63 + 64 entries
+constexpr int REGION0_FLOATS = S0_MAX * 3 + PAR_MAX; // + one pad dword per parent (bank spread)
+constexpr int REGION1_FLOATS = S1_MAX * 3 + PAR_MAX;
+constexpr int SLOT_FLOATS = REGION0_FLOATS + REGION1_FLOATS;
+// the parent-lane table, the group results and the 8x8 u8 tile alias the (then idle) leaf slot region
+constexpr int WAVE_LDS_FLOATS = SLOT_FLOATS + (Q1_CAP + Q2_CAP) * QF;
+static_assert(REGION1_FLOATS >= 64 + PAR_MAX * 3 + 48, "aliases must fit");
+
+// Diagnostic build only (-DSKR_STAMPS=1): per-phase cycle shares, summed over waves into
+// counters[4*SKR_COUNTER_SHARDS + phase].  Compiles to nothing otherwise.
+#if defined(SKR_STAMPS) && SKR_STAMPS
+#define STAMP_DECL unsigned long long st_t0 = __builtin_readcyclecounter(); unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP_ARG , unsigned long long &st_t0, unsigned long long (&st_acc)[8]
+#define STAMP_PASS , st_t0, st_acc
+#define STAMP(phase) do { const unsigned long long st_now = __builtin_readcyclecounter(); st_acc[phase] += st_now - st_t0; st_t0 = st_now; } while(0)
+#else
+#define STAMP_DECL
+#define STAMP_ARG
+#define STAMP_PASS
+#define STAMP(phase)
+#endif
 
 SKR_DEV void wave_lds_fence()
 { // producer and consumer lanes are in the same wave: ordering only, no instruction
@@ -51,6 +79,7 @@ SKR_DEV int lanes_below(unsigned long long m)
 
 struct Queue { // ring of sphere-hit records in LDS, SoA by field; head/count are wave-uniform
 	float *base;
+	int cap;
 	int head, count;
 };
 
@@ -67,36 +96,41 @@ SKR_DEV void q_push(Queue &q, bool pred, const HitRec &h)
 	const unsigned long long m = __ballot(pred);
 	if(pred)
 	{
-		const int e = (q.head + q.count + lanes_below(m)) & (Q_CAP - 1);
+		int e = q.head + q.count + lanes_below(m); // head < cap, count + 64 <= cap + 63
+		e -= (e >= q.cap) ? q.cap : 0;
 		float *r = q.base + e;
-		r[0 * Q_CAP] = h.d.x;
-		r[1 * Q_CAP] = h.d.y;
-		r[2 * Q_CAP] = h.d.z;
-		r[3 * Q_CAP] = h.b;
-		r[4 * Q_CAP] = h.D;
-		r[5 * Q_CAP] = __uint_as_float(h.ids);
-		r[6 * Q_CAP] = __int_as_float(h.slot);
-		r[7 * Q_CAP] = h.r1;
+		r[0 * q.cap] = h.d.x;
+		r[1 * q.cap] = h.d.y;
+		r[2 * q.cap] = h.d.z;
+		r[3 * q.cap] = h.b;
+		r[4 * q.cap] = h.D;
+		r[5 * q.cap] = __uint_as_float(h.ids);
+		r[6 * q.cap] = __int_as_float(h.slot);
+		r[7 * q.cap] = h.r1;
 	}
 	q.count = uni(q.count + (int) __popcll(m));
 }
 
 SKR_DEV HitRec q_read(const Queue &q, int j)
 {
-	const float *r = q.base + ((q.head + j) & (Q_CAP - 1));
+	int e = q.head + j;
+	e -= (e >= q.cap) ? q.cap : 0;
+	const float *r = q.base + e;
 	HitRec h;
-	h.d = mk3(r[0 * Q_CAP], r[1 * Q_CAP], r[2 * Q_CAP]);
-	h.b = r[3 * Q_CAP];
-	h.D = r[4 * Q_CAP];
-	h.ids = __float_as_uint(r[5 * Q_CAP]);
-	h.slot = __float_as_int(r[6 * Q_CAP]);
-	h.r1 = r[7 * Q_CAP];
+	h.d = mk3(r[0 * q.cap], r[1 * q.cap], r[2 * q.cap]);
+	h.b = r[3 * q.cap];
+	h.D = r[4 * q.cap];
+	h.ids = __float_as_uint(r[5 * q.cap]);
+	h.slot = __float_as_int(r[6 * q.cap]);
+	h.r1 = r[7 * q.cap];
 	return h;
 }
 
 SKR_DEV void q_drop(Queue &q, int m)
 {
-	q.head = uni((q.head + m) & (Q_CAP - 1));
+	int nh = q.head + m;
+	nh -= (nh >= q.cap) ? q.cap : 0;
+	q.head = uni(nh);
 	q.count = uni(q.count - m);
 }
 
@@ -161,15 +195,16 @@ SKR_DEV int closest_sphere_deferred(const SceneView &sv, f3 o, f3 d, const RayFi
 }
 
 // One round of child rays: lane = task task0 + lane = (parent k, child i) of the parents
-// held in lanes [0, np).  The contribution slot of (k, i) is slots[sbase + k*(3N+1) + 3i].
-SKR_DEV void child_round(const Wave &w, const Parent &par, int np, int task0, int sbase, Queue &q, Counters &cn)
+// held in lanes [kbase, kbase+np).  The contribution slot of (k, i) is slots[sbase + k*(3N+1) + 3i].
+SKR_DEV void child_round(const Wave &w, const Parent &par, int kbase, int np, int task0, int sbase, Queue &q, Counters &cn)
 {
 	const int t = task0 + w.lane;
 	const bool valid = t < np * w.N;
-	const int k = valid ? (int) (((uint32_t) t * w.magicN) >> 24) : 0;
+	const int k = valid ? (int) (((uint32_t) t * w.magicN) >> 24) : 0; // parent within the window [kbase, kbase+np)
 	const int i = t - k * w.N;
-	const f3 co = shfl3(par.co, k), N = shfl3(par.N, k), nt = shfl3(par.nt, k), nb = shfl3(par.nb, k);
-	const uint32_t pixel = (uint32_t) __shfl((int) par.pixel, k, 64), node = (uint32_t) __shfl((int) par.node, k, 64);
+	const int kl = kbase + k;                                           // lane that holds the parent
+	const f3 co = shfl3(par.co, kl), N = shfl3(par.N, kl), nt = shfl3(par.nt, kl), nb = shfl3(par.nb, kl);
+	const uint32_t pixel = (uint32_t) __shfl((int) par.pixel, kl, 64), node = (uint32_t) __shfl((int) par.node, kl, 64);
 	HitRec h;
 	h.d = mk3(0, 0, 0);
 	h.b = h.D = h.r1 = 0.0f;
@@ -209,7 +244,7 @@ SKR_DEV void child_round(const Wave &w, const Parent &par, int np, int task0, in
 			h.d = d;
 			h.b = b;
 			h.D = D;
-			h.ids = (uint32_t) sph | ((uint32_t) k << 16) | ((uint32_t) i << 24);
+			h.ids = (uint32_t) sph | ((uint32_t) kl << 16) | ((uint32_t) i << 24);
 			h.r1 = r1;
 		}
 	}
@@ -255,11 +290,12 @@ SKR_DEV f3 sum_slots(const Wave &w, int sbase, int k)
 	return total;
 }
 
-// DEPTH == 3: m <= A queued level-1 hits become the active parents (lanes [0,m)); their
+// DEPTH == 3: m <= 64 queued level-1 hits become the active parents (lanes [0,m)); their
 // N leaf rays each are traced in rounds, leaf hits are shaded in batches of 64, and each
 // parent's result is deposited in ITS parent's slot (raytrace.h:130).
-SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, const Parent &par0, int m, Counters &cn)
+SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, const Parent &par0, int m, Counters &cn STAMP_ARG)
 {
+	STAMP(1);
 	wave_lds_fence();
 	const bool act = w.lane < m;
 	const HitRec h = q_read(q1, act ? w.lane : 0);
@@ -285,32 +321,47 @@ SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, const Pare
 		tangent_basis(par1.N, par1.nt, par1.nb);
 		par1.co = add_scalar(P, 0.00001f);
 	}
-	const int sbase1 = S0_MAX * 3 + 64;
-	const int ntasks = m * w.N;
-	for(int task0 = 0; task0 < ntasks; task0 += 64)
+	const int sbase1 = REGION0_FLOATS;
+	STAMP(4);
+	// the m parents were shaded together (full-width); their leaf rays go through the slot area a
+	// window of AW parents at a time
+	const int AW = uni(S1_MAX / w.N < PAR_MAX ? S1_MAX / w.N : PAR_MAX);
+	for(int w0 = 0; w0 < m; w0 += AW)
 	{
-		child_round(w, par1, m, task0, sbase1, q2, cn);
-		while(q2.count >= 64) shade_leaf_batch(w, q2, par1, 64, cn);
+		const int mw = uni(m - w0 < AW ? m - w0 : AW);
+		const int ntasks = mw * w.N;
+		for(int task0 = 0; task0 < ntasks; task0 += 64)
+		{
+			child_round(w, par1, w0, mw, task0, sbase1, q2, cn);
+			STAMP(2);
+			// one call site (code size): full batches as they form, the remainder after the window's last round
+			const bool last = task0 + 64 >= ntasks;
+			while(q2.count >= 64 || (last && q2.count > 0))
+			{
+				shade_leaf_batch(w, q2, par1, q2.count < 64 ? q2.count : 64, cn);
+				STAMP(3);
+			}
+		}
+		wave_lds_fence();
+		if(act && w.lane >= w0 && w.lane < w0 + mw)
+		{
+			f3 total = sum_slots(w, sbase1, w.lane - w0);
+			total = total / (float) w.N;
+			const f3 colour = (direct1 / (float) 3.14159265358979323846 + total * 2.0f) * ld3(w.sv.kd[sph1]);
+			const f3 contrib = (colour * h.r1) / w.pdf;
+			float *s = w.slots + h.slot;
+			s[0] = contrib.x;
+			s[1] = contrib.y;
+			s[2] = contrib.z;
+		}
+		wave_lds_fence();
+		STAMP(5);
 	}
-	while(q2.count > 0) shade_leaf_batch(w, q2, par1, q2.count < 64 ? q2.count : 64, cn);
-	wave_lds_fence();
-	if(act)
-	{
-		f3 total = sum_slots(w, sbase1, w.lane);
-		total = total / (float) w.N;
-		const f3 colour = (direct1 / (float) 3.14159265358979323846 + total * 2.0f) * ld3(w.sv.kd[sph1]);
-		const f3 contrib = (colour * h.r1) / w.pdf;
-		float *s = w.slots + h.slot;
-		s[0] = contrib.x;
-		s[1] = contrib.y;
-		s[2] = contrib.z;
-	}
-	wave_lds_fence();
 }
 
 // One sample of every pixel of the wave's tile: raytrace.h:139-227 at depth DEPTH.
 template <int DEPTH>
-SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pixel, Queue &q1, Queue &q2, int *lane_tbl, float *gres, Counters &cn)
+SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pixel, Queue &q1, Queue &q2, int *lane_tbl, float *gres, Counters &cn STAMP_ARG)
 {
 	const RenderParams &p = *w.p;
 	// ---- primary rays: one lane per pixel
@@ -346,6 +397,7 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 			}
 		}
 	}
+	STAMP(0);
 	if(!p.monte_carlo) return result;
 
 	f3 indirect = mk3(0, 0, 0); // sum of the children's terms; stays 0 when they are all shade(depth 0)
@@ -354,8 +406,7 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 		const unsigned long long M0 = __ballot(hit);
 		const int n0 = (int) __popcll(M0);
 		const int rank = lanes_below(M0);
-		const int G = uni(S0_MAX / (w.N > 0 ? w.N : 1) < 64 ? S0_MAX / (w.N > 0 ? w.N : 1) : 64);
-		const int A = uni(S1_MAX / (w.N > 0 ? w.N : 1) < 64 ? S1_MAX / (w.N > 0 ? w.N : 1) : 64);
+		const int G = uni(S0_MAX / (w.N > 0 ? w.N : 1) < PAR_MAX ? S0_MAX / (w.N > 0 ? w.N : 1) : PAR_MAX);
 		for(int g0 = 0; g0 < n0 && w.N > 0; g0 += G)
 		{
 			const int gp = uni(n0 - g0 < G ? n0 - g0 : G);
@@ -374,24 +425,18 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 			const int ntasks = gp * w.N;
 			for(int task0 = 0; task0 < ntasks; task0 += 64)
 			{
+				const bool last = task0 + 64 >= ntasks;
 				if constexpr(DEPTH == 2)
 				{
-					child_round(w, par0, gp, task0, 0, q2, cn);
-					while(q2.count >= 64) shade_leaf_batch(w, q2, par0, 64, cn);
+					child_round(w, par0, 0, gp, task0, 0, q2, cn);
+					while(q2.count >= 64 || (last && q2.count > 0)) shade_leaf_batch(w, q2, par0, q2.count < 64 ? q2.count : 64, cn);
 				}
 				else
 				{
-					child_round(w, par0, gp, task0, 0, q1, cn);
-					while(q1.count >= A) expand_level1_batch(w, q1, q2, par0, A, cn);
+					child_round(w, par0, 0, gp, task0, 0, q1, cn);
+					STAMP(1);
+					while(q1.count >= 64 || (last && q1.count > 0)) expand_level1_batch(w, q1, q2, par0, q1.count < 64 ? q1.count : 64, cn STAMP_PASS);
 				}
-			}
-			if constexpr(DEPTH == 2)
-			{
-				while(q2.count > 0) shade_leaf_batch(w, q2, par0, q2.count < 64 ? q2.count : 64, cn);
-			}
-			else
-			{
-				while(q1.count > 0) expand_level1_batch(w, q1, q2, par0, q1.count < A ? q1.count : A, cn);
 			}
 			wave_lds_fence();
 			if(w.lane < gp)
@@ -419,7 +464,7 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 // One workgroup = 4 independent waves; wave w of block (bx, by) owns the 8x8 pixel tile
 // (2*bx + (w&1), 2*by + (w>>1)).  Dynamic LDS: scene SoA (shared, staged once) | 4 wave areas.
 template <int DEPTH>
-__global__ __launch_bounds__(256, 2) void skr_wave_kernel(const RenderParams p)
+__global__ __launch_bounds__(256, SKR_WAVE_OCC) void skr_wave_kernel(const RenderParams p)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
@@ -448,10 +493,10 @@ __global__ __launch_bounds__(256, 2) void skr_wave_kernel(const RenderParams p)
 	w.magicN = (uint32_t) (((1u << 24) + (uint32_t) (w.N > 0 ? w.N : 1) - 1u) / (uint32_t) (w.N > 0 ? w.N : 1));
 	w.aa = 0;
 	w.pdf = (float) (1 / 3.14159265358979323846);
-	Queue q1{wbase + SLOT_FLOATS, 0, 0}, q2{wbase + SLOT_FLOATS + Q_CAP * QF, 0, 0};
-	int *lane_tbl = reinterpret_cast<int *>(wbase + SLOT_FLOATS + 2 * Q_CAP * QF);
-	float *gres = wbase + SLOT_FLOATS + 2 * Q_CAP * QF + 64;
-	unsigned char *s_tile = reinterpret_cast<unsigned char *>(gres + 64 * 3);
+	Queue q1{wbase + SLOT_FLOATS, Q1_CAP, 0, 0}, q2{wbase + SLOT_FLOATS + Q1_CAP * QF, Q2_CAP, 0, 0};
+	int *lane_tbl = reinterpret_cast<int *>(wbase + REGION0_FLOATS); // aliases of the leaf slot region, see above
+	float *gres = wbase + REGION0_FLOATS + 64;
+	unsigned char *s_tile = reinterpret_cast<unsigned char *>(gres + PAR_MAX * 3);
 
 	const int lx = lane & 7, ly = lane >> 3;
 	const int x0 = (blockIdx.x * 2 + (wave & 1)) * 8;
@@ -464,6 +509,7 @@ __global__ __launch_bounds__(256, 2) void skr_wave_kernel(const RenderParams p)
 	const uint32_t pixel = y * (uint32_t) p.width + (uint32_t) x;
 
 	Counters cn{0, 0, 0};
+	STAMP_DECL;
 	f3 px = mk3(0, 0, 0);
 	if(p.grid_size > 0)
 	{ // main.cpp:140-166
@@ -477,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void skr_wave_kernel(const RenderParams p)
 			const float u = ((2 * (((float) x + r) * p.inv_width) - 1) * p.angle) * p.aspect;
 			const float v = (1 - 2 * (((float) (int) y + r) * p.inv_height)) * p.angle;
 			const f3 dir = (p.cam_dir + p.cam_right * u) + p.cam_up * v;
-			px = px + shade_tile_sample<DEPTH>(w, valid, p.cam_pos, dir, pixel, q1, q2, lane_tbl, gres, cn);
+			px = px + shade_tile_sample<DEPTH>(w, valid, p.cam_pos, dir, pixel, q1, q2, lane_tbl, gres, cn STAMP_PASS);
 		}
 		px = px / (float) ns2;
 	}
@@ -486,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void skr_wave_kernel(const RenderParams p)
 		const float u = (float) (((2 * (((double) x + 0.5) * (double) p.inv_width) - 1) * (double) p.angle) * (double) p.aspect);
 		const float v = (float) ((1 - 2 * (((double) (int) y + 0.5) * (double) p.inv_height)) * (double) p.angle);
 		const f3 dir = (p.cam_dir + p.cam_right * u) + p.cam_up * v;
-		px = shade_tile_sample<DEPTH>(w, valid, p.cam_pos, dir, pixel, q1, q2, lane_tbl, gres, cn);
+		px = shade_tile_sample<DEPTH>(w, valid, p.cam_pos, dir, pixel, q1, q2, lane_tbl, gres, cn STAMP_PASS);
 	}
 
 	if(valid && p.rgbf)
@@ -527,6 +573,11 @@ __global__ __launch_bounds__(256, 2) void skr_wave_kernel(const RenderParams p)
 			dst[2] = t[2];
 		}
 	}
+#if defined(SKR_STAMPS) && SKR_STAMPS
+	STAMP(6);
+	if(p.counters && lane == 0)
+		for(int k = 0; k < 8; k++) atomicAdd(&p.counters[4u * SKR_COUNTER_SHARDS + k], st_acc[k]);
+#endif
 	if(p.counters)
 	{
 		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays);
@@ -546,7 +597,7 @@ size_t skr_wave_lds_bytes(const RenderParams &p) { return ((size_t) 4 * p.n_sphe
 // The streaming kernel covers --depth 1..3, gillum <= 256, <= 65535 spheres.
 bool skr_wave_supported(const RenderParams &p)
 {
-	return p.max_depth >= 1 && p.max_depth <= 3 && p.num_path_traces <= S0_MAX && p.n_spheres < 65536;
+	return p.max_depth >= 1 && p.max_depth <= 3 && p.num_path_traces <= S0_MAX && p.n_spheres < 65536; // i < 256 in HitRec.ids
 }
 
 template <int D>

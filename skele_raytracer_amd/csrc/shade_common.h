@@ -113,22 +113,43 @@ SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float t
 	return hit;
 }
 
-// utils.h:42-58: any sphere with 1 < t < inf along the (unbounded) shadow ray.
-SKR_DEV bool occluded(const SceneView &sv, f3 P, f3 L)
+// utils.h:42-58: any sphere with 1 < t < inf along the (unbounded) shadow ray; two lights at a
+// time, because both shadow rays start at the same point and share e and c per sphere.
+SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second, bool &occ0, bool &occ1)
 {
 	const f3 o = add_scalar(P, 0.000001f);
-	const RayFilt f = make_filt(L);
-	bool occ = false;
+	const RayFilt f0 = make_filt(L0), f1 = make_filt(L1);
+	occ0 = false;
+	occ1 = !second;
 	float4 g_next = sv.geom[0];
 	for(int i = 0; i < sv.ns; i++)
 	{
 		const float4 g = g_next;
 		g_next = sv.geom[i + 1];
+		const f3 e = o - ld3(g);
+		const float c = dot3(e, e) - g.w;
 		float lo, hi, b, D;
-		if(!occ) occ = sphere_bracket(o, L, f, g, lo, hi, b, D);
-		if(__all(occ)) break;
+		if(!occ0) occ0 = bracket_from_ec(e, c, L0, f0, lo, hi, b, D);
+		if(!occ1) occ1 = bracket_from_ec(e, c, L1, f1, lo, hi, b, D);
+		if(__all(occ0 && occ1)) break;
 	}
-	return occ;
+	if(!second) occ1 = false;
+}
+
+struct LightTerm { // the per-light quantities of blinn_phong.h:67-72 / :100-117
+	f3 L, lc;
+	float len;
+};
+
+SKR_DEV LightTerm light_term(const SceneView &sv, int i, f3 P)
+{
+	LightTerm t;
+	const f3 lp = ld3(sv.lights[2 * i]);
+	t.lc = ld3(sv.lights[2 * i + 1]);
+	const f3 to_l = lp - P;
+	t.len = sk_sqrtf(sqr3(to_l));
+	t.L = to_l * sk_divf(1.0f, t.len);
+	return t;
 }
 
 // raytrace.h:36-44 = bp::ambient (blinn_phong.h:13) + diffuse (:47) + specular (:90).
@@ -139,26 +160,29 @@ SKR_DEV f3 direct_light(const SceneView &sv, const RenderParams &p, int sph, f3 
 	const float4 ambp = sv.amb[sph];
 	f3 diffuse = mk3(0, 0, 0), specular = mk3(0, 0, 0);
 	const f3 view = normalize3(p.cam_pos - P); // always the camera (blinn_phong.h:93)
-	for(int i = 0; i < sv.nl; i++)
+	for(int i = 0; i < sv.nl; i += 2)
 	{
-		const f3 lp = ld3(sv.lights[2 * i]), lc = ld3(sv.lights[2 * i + 1]);
-		const f3 to_l = lp - P;
-		const float sq = sqr3(to_l);
-		const float len = sk_sqrtf(sq);
-		const f3 L = to_l * sk_divf(1.0f, len);
-		bool lit = true;
+		const bool second = i + 1 < sv.nl;
+		const LightTerm t0 = light_term(sv, i, P), t1 = light_term(sv, second ? i + 1 : i, P);
+		bool occ0 = false, occ1 = false;
 		if(p.use_shadows)
 		{
-			cn.shadow_rays++;
-			lit = !occluded(sv, P, L);
+			cn.shadow_rays += second ? 2u : 1u;
+			occluded_pair(sv, P, t0.L, t1.L, second, occ0, occ1);
 		}
-		if(lit)
+#pragma unroll
+		for(int k = 0; k < 2; k++)
 		{
-			const float intensity = sk_divf(1.0f, len * len); // 1/powf(|d|,2) == 1/(d*d)
-			diffuse = diffuse + ((kd * lc) * intensity) * max0(dot3(N, L));
-			const f3 vl = view + L;
-			const f3 H = vl / length3(vl);
-			specular = specular + ((ks * lc) * intensity) * powf_spec(max0(dot3(N, H)), ambp.w);
+			const LightTerm &t = k ? t1 : t0;
+			const bool lit = k ? (second && !occ1) : !occ0;
+			if(lit)
+			{
+				const float intensity = sk_divf(1.0f, t.len * t.len); // 1/powf(|d|,2) == 1/(d*d)
+				diffuse = diffuse + ((kd * t.lc) * intensity) * max0(dot3(N, t.L));
+				const f3 vl = view + t.L;
+				const f3 H = vl / length3(vl);
+				specular = specular + ((ks * t.lc) * intensity) * powf_spec(max0(dot3(N, H)), ambp.w);
+			}
 		}
 	}
 	f3 total = mk3(0, 0, 0);
