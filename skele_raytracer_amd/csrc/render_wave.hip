@@ -29,26 +29,25 @@
 
 namespace {
 
-#ifndef SKR_WAVE_OCC
-#define SKR_WAVE_OCC 3       // waves per SIMD the LDS/VGPR budget below is sized for
-#endif
+// Two LDS/VGPR budgets are compiled: OCC = waves per SIMD the workgroup's footprint allows.
+//   Cfg<3>: 12.5 KB of LDS per wave, <= 168 VGPRs  — best for gillum <= 32 (more waves hide latency)
+//   Cfg<2>: 17.5 KB of LDS per wave, <= 256 VGPRs  — bigger slot windows, best for large gillum
 constexpr int QF = 8;        // dwords per queue record: d.xyz, b, D, packed ids, slot, r1
-#if SKR_WAVE_OCC >= 3
-constexpr int S0_MAX = 128;  // level-1 contribution slots of one parent group  (G * N <= S0_MAX)
-constexpr int S1_MAX = 256;  // leaf contribution slots of one active batch      (A * N <= S1_MAX)
-#else
-constexpr int S0_MAX = 256;
-constexpr int S1_MAX = 512;
-#endif
 constexpr int PAR_MAX = 32;  // parents per group / per leaf-slot window (G, AW <= PAR_MAX)
 constexpr int Q1_CAP = 128;  // level-1 hits waiting to become parents: <= 63 + 64 entries
 constexpr int Q2_CAP = 128;  // leaf hits waiting to be shaded: <= 63 + 64 entries
-constexpr int REGION0_FLOATS = S0_MAX * 3 + PAR_MAX; // + one pad dword per parent (bank spread)
-constexpr int REGION1_FLOATS = S1_MAX * 3 + PAR_MAX;
-constexpr int SLOT_FLOATS = REGION0_FLOATS + REGION1_FLOATS;
-// the parent-lane table, the group results and the 8x8 u8 tile alias the (then idle) leaf slot region
-constexpr int WAVE_LDS_FLOATS = SLOT_FLOATS + (Q1_CAP + Q2_CAP) * QF;
-static_assert(REGION1_FLOATS >= 64 + PAR_MAX * 3 + 48, "aliases must fit");
+template <int OCC>
+struct Cfg {
+	static constexpr int S0_MAX = (OCC >= 3) ? 128 : 256; // level-1 contribution slots of one parent group (G * N <= S0_MAX)
+	static constexpr int S1_MAX = (OCC >= 3) ? 256 : 512; // leaf contribution slots of one window          (AW * N <= S1_MAX)
+	static constexpr int REGION0_FLOATS = S0_MAX * 3 + PAR_MAX; // + one pad dword per parent (bank spread)
+	static constexpr int REGION1_FLOATS = S1_MAX * 3 + PAR_MAX;
+	static constexpr int SLOT_FLOATS = REGION0_FLOATS + REGION1_FLOATS;
+	// the parent-lane table, the group results and the 8x8 u8 tile alias the (then idle) leaf slot region
+	static constexpr int WAVE_LDS_FLOATS = SLOT_FLOATS + (Q1_CAP + Q2_CAP) * QF;
+	static_assert(REGION1_FLOATS >= 64 + PAR_MAX * 3 + 48, "aliases must fit");
+};
+constexpr int GILLUM_MAX = 256; // child index is 8 bits in HitRec.ids; Cfg<2>::S0_MAX
 
 // Diagnostic build only (-DSKR_STAMPS=1): per-phase cycle shares, summed over waves into
 // counters[4*SKR_COUNTER_SHARDS + phase].  Compiles to nothing otherwise.
@@ -151,6 +150,7 @@ struct Wave {
 	uint32_t magicN;  // ceil(2^24 / N): t / N == (t * magicN) >> 24 for t < 65536, N <= 256
 	uint32_t aa;
 	float pdf;
+	int s0_max, s1_max, sbase1; // Cfg<OCC> of this kernel instance
 };
 
 // closest accepted sphere without forming the winner's exact t2 (done later, in the
@@ -321,11 +321,11 @@ SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, const Pare
 		tangent_basis(par1.N, par1.nt, par1.nb);
 		par1.co = add_scalar(P, 0.00001f);
 	}
-	const int sbase1 = REGION0_FLOATS;
+	const int sbase1 = w.sbase1;
 	STAMP(4);
 	// the m parents were shaded together (full-width); their leaf rays go through the slot area a
 	// window of AW parents at a time
-	const int AW = uni(S1_MAX / w.N < PAR_MAX ? S1_MAX / w.N : PAR_MAX);
+	const int AW = uni(w.s1_max / w.N < PAR_MAX ? w.s1_max / w.N : PAR_MAX);
 	for(int w0 = 0; w0 < m; w0 += AW)
 	{
 		const int mw = uni(m - w0 < AW ? m - w0 : AW);
@@ -406,7 +406,7 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 		const unsigned long long M0 = __ballot(hit);
 		const int n0 = (int) __popcll(M0);
 		const int rank = lanes_below(M0);
-		const int G = uni(S0_MAX / (w.N > 0 ? w.N : 1) < PAR_MAX ? S0_MAX / (w.N > 0 ? w.N : 1) : PAR_MAX);
+		const int G = uni(w.s0_max / (w.N > 0 ? w.N : 1) < PAR_MAX ? w.s0_max / (w.N > 0 ? w.N : 1) : PAR_MAX);
 		for(int g0 = 0; g0 < n0 && w.N > 0; g0 += G)
 		{
 			const int gp = uni(n0 - g0 < G ? n0 - g0 : G);
@@ -463,8 +463,8 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 
 // One workgroup = 4 independent waves; wave w of block (bx, by) owns the 8x8 pixel tile
 // (2*bx + (w&1), 2*by + (w>>1)).  Dynamic LDS: scene SoA (shared, staged once) | 4 wave areas.
-template <int DEPTH>
-__global__ __launch_bounds__(256, SKR_WAVE_OCC) void skr_wave_kernel(const RenderParams p)
+template <int DEPTH, int OCC>
+__global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
@@ -483,7 +483,8 @@ __global__ __launch_bounds__(256, SKR_WAVE_OCC) void skr_wave_kernel(const Rende
 	__syncthreads(); // the only workgroup barrier: from here on the four waves never meet again
 
 	const int wave = tid >> 6, lane = tid & 63;
-	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * WAVE_LDS_FLOATS;
+	using C = Cfg<OCC>;
+	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * C::WAVE_LDS_FLOATS;
 	Wave w;
 	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl};
 	w.p = &p;
@@ -493,9 +494,12 @@ __global__ __launch_bounds__(256, SKR_WAVE_OCC) void skr_wave_kernel(const Rende
 	w.magicN = (uint32_t) (((1u << 24) + (uint32_t) (w.N > 0 ? w.N : 1) - 1u) / (uint32_t) (w.N > 0 ? w.N : 1));
 	w.aa = 0;
 	w.pdf = (float) (1 / 3.14159265358979323846);
-	Queue q1{wbase + SLOT_FLOATS, Q1_CAP, 0, 0}, q2{wbase + SLOT_FLOATS + Q1_CAP * QF, Q2_CAP, 0, 0};
-	int *lane_tbl = reinterpret_cast<int *>(wbase + REGION0_FLOATS); // aliases of the leaf slot region, see above
-	float *gres = wbase + REGION0_FLOATS + 64;
+	w.s0_max = C::S0_MAX;
+	w.s1_max = C::S1_MAX;
+	w.sbase1 = C::REGION0_FLOATS;
+	Queue q1{wbase + C::SLOT_FLOATS, Q1_CAP, 0, 0}, q2{wbase + C::SLOT_FLOATS + Q1_CAP * QF, Q2_CAP, 0, 0};
+	int *lane_tbl = reinterpret_cast<int *>(wbase + C::REGION0_FLOATS); // aliases of the leaf slot region, see Cfg
+	float *gres = wbase + C::REGION0_FLOATS + 64;
 	unsigned char *s_tile = reinterpret_cast<unsigned char *>(gres + PAR_MAX * 3);
 
 	const int lx = lane & 7, ly = lane >> 3;
@@ -592,21 +596,29 @@ __global__ __launch_bounds__(256, SKR_WAVE_OCC) void skr_wave_kernel(const Rende
 	}
 }
 
-size_t skr_wave_lds_bytes(const RenderParams &p) { return ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + (size_t) 4 * WAVE_LDS_FLOATS * 4; }
+// gillum <= 32: the 3-waves-per-SIMD budget wins (3.6 vs 4.1 ms at N = 16); above, the larger slot
+// windows of the 2-wave budget do (21.9 vs 35 ms at N = 64, 960x540).  Measured: DESIGN.md §6.
+static int wave_occ_for(const RenderParams &p) { return (p.monte_carlo && p.num_path_traces > 32) ? 2 : 3; }
+
+size_t skr_wave_lds_bytes(const RenderParams &p)
+{
+	const size_t per_wave = (wave_occ_for(p) == 3 ? Cfg<3>::WAVE_LDS_FLOATS : Cfg<2>::WAVE_LDS_FLOATS) * sizeof(float);
+	return ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 4 * per_wave;
+}
 
 // The streaming kernel covers --depth 1..3, gillum <= 256, <= 65535 spheres.
 bool skr_wave_supported(const RenderParams &p)
 {
-	return p.max_depth >= 1 && p.max_depth <= 3 && p.num_path_traces <= S0_MAX && p.n_spheres < 65536; // i < 256 in HitRec.ids
+	return p.max_depth >= 1 && p.max_depth <= 3 && p.num_path_traces <= GILLUM_MAX && p.n_spheres < 65536;
 }
 
-template <int D>
+template <int D, int OCC>
 static hipError_t launch_wave_depth(const RenderParams &p, dim3 grid, size_t lds, hipStream_t stream)
 {
 	// > 64 KiB of dynamic LDS per workgroup has to be opted into
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(skr_wave_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(skr_wave_kernel<D, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 	if(e != hipSuccess) return e;
-	hipLaunchKernelGGL(skr_wave_kernel<D>, grid, dim3(256), lds, stream, p);
+	hipLaunchKernelGGL((skr_wave_kernel<D, OCC>), grid, dim3(256), lds, stream, p);
 	return hipGetLastError();
 }
 
@@ -614,11 +626,12 @@ hipError_t skr_launch_wave(const RenderParams &p, hipStream_t stream)
 {
 	const dim3 grid((p.width + 15) / 16, (p.out_rows + 15) / 16);
 	const size_t lds = skr_wave_lds_bytes(p);
+	const bool occ3 = wave_occ_for(p) == 3;
 	switch(p.max_depth)
 	{
-		case 1: return launch_wave_depth<1>(p, grid, lds, stream);
-		case 2: return launch_wave_depth<2>(p, grid, lds, stream);
-		case 3: return launch_wave_depth<3>(p, grid, lds, stream);
+		case 1: return launch_wave_depth<1, 3>(p, grid, lds, stream);
+		case 2: return occ3 ? launch_wave_depth<2, 3>(p, grid, lds, stream) : launch_wave_depth<2, 2>(p, grid, lds, stream);
+		case 3: return occ3 ? launch_wave_depth<3, 3>(p, grid, lds, stream) : launch_wave_depth<3, 2>(p, grid, lds, stream);
 		default: return hipErrorInvalidValue;
 	}
 }
