@@ -164,3 +164,29 @@ def test_unsupported_configs_fail_loudly(gpu):
         r.render(skr.Options(64, 36, depth=0))
     with pytest.raises(skr.SkrError, match="depth"):
         r.render(skr.Options(64, 36, gillum=2, depth=9))
+
+
+def test_cli_drop_in_writes_the_same_ppm(gpu, oracle, tmp_path):
+    """bin/raytracer (reference command line, main.cpp:230-413) end to end: flags anywhere in argv,
+    unknown tokens ignored (`--shadow on`), P6 output byte-identical to the oracle's frame."""
+    import os
+    import subprocess
+    from conftest import ROOT, read_ppm_bytes
+    exe = os.path.join(ROOT, "bin", "raytracer")
+    assert os.path.exists(exe), "run `make cli`"
+    out = str(tmp_path / "cli.ppm")
+    cmd = [exe, "--output", out, "--gillum", "4", "--shadow", "on", "--width", "160", "--height", "90", "--parallel", "true",
+           "--path", scene_path("spheres2.scn"), "--seed", "7", "bogus-token"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert "WROTE TO PPM" in res.stdout and "Monte carlo: 1" in res.stdout and "Sphere as position" in res.stdout
+    got = read_ppm_bytes(open(out, "rb").read())
+    want, _, _ = oracle.render(scene_path("spheres2.scn"), 160, 90, gillum=4, shadow=True, seed=7)
+    assert np.array_equal(got, want)
+    # usage errors: message on stderr, exit status 0 (main.cpp:381-391)
+    res = subprocess.run([exe, "--output", out], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0 and "no scene file was passed" in res.stderr
+    res = subprocess.run([exe, "--path", scene_path("spheres2.scn"), "--output", out, "--depth", "0"], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0 and "depth takes a positive int" in res.stderr
+    res = subprocess.run([exe, "--path", str(tmp_path / "nope.scn"), "--output", out], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0 and "Can't open file" in res.stdout
