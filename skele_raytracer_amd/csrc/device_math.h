@@ -246,6 +246,70 @@ SKR_DEV bool bracket_from_ec(f3 e, float c, f3 d, const RayFilt &f, float &lo, f
 	return true;
 }
 
+// ---- two rays with a common origin, evaluated with packed binary32 arithmetic ----
+// v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 do two IEEE binary32 operations per lane per
+// instruction with the same rounding as the scalar forms, so every component below is the
+// same value sphere_bracket() would produce for that ray alone.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct RayPair {
+	f2 dx, dy, dz;              // directions of ray 0 / ray 1, component-wise
+	f2 two_a, four_a, inv2a, k_err;
+	bool sane0, sane1;
+};
+
+SKR_DEV RayPair make_pair(f3 d0, f3 d1)
+{
+	RayPair r;
+	r.dx = f2{d0.x, d1.x};
+	r.dy = f2{d0.y, d1.y};
+	r.dz = f2{d0.z, d1.z};
+	const f2 a = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz; // dot3(d, d)
+	r.two_a = 2.0f * a;
+	r.four_a = 4.0f * a;
+	r.inv2a = f2{__builtin_amdgcn_rcpf(r.two_a.x), __builtin_amdgcn_rcpf(r.two_a.y)};
+	r.k_err = r.inv2a * 0x1p-20f;
+	r.sane0 = (a.x > 1e-18f) && (a.x < 1e18f);
+	r.sane1 = (a.y > 1e-18f) && (a.y < 1e18f);
+	return r;
+}
+
+// b and D of utils.h:116-118 / :89 for both rays against one sphere given the shared e, c.
+SKR_DEV void pair_bD(const RayPair &r, f3 e, float c, f2 &b, f2 &D)
+{
+	b = 2.0f * ((r.dx * e.x + r.dy * e.y) + r.dz * e.z);
+	D = b * b - r.four_a * c;
+}
+
+// Brackets [lo, hi] of t2 for both rays (valid where D >= 0 and b < 0).
+SKR_DEV void pair_bracket(const RayPair &r, f2 b, f2 D, f2 &lo, f2 &hi)
+{
+	const f2 s = f2{__builtin_amdgcn_sqrtf(D.x), __builtin_amdgcn_sqrtf(D.y)};
+	const f2 num = (-b) - s;
+	const f2 ta = num * r.inv2a;
+	const f2 abs_num = __builtin_elementwise_max(num, -num);
+	const f2 abs_ta = __builtin_elementwise_max(ta, -ta);
+	const f2 E = abs_ta * 0x1p-22f + (s + abs_num) * r.k_err; // bound only: its own rounding is covered by the 4x slack
+	lo = ta - E;
+	hi = ta + E;
+}
+
+// Classify one component: returns accept; *resolved_t is set (and lo = hi = t) when the exact form had to decide.
+SKR_DEV bool bracket_decide(bool sane, float two_a, float b, float D, float &lo, float &hi)
+{
+	const bool normal = sane && (D > 1e-30f) && (b < -1e-15f);
+	const bool certain_accept = normal && (lo > 1.0f) && (hi < 3.0e38f);
+	const bool certain_reject = normal && (hi < 1.0f);
+	if(certain_reject) return false;
+	if(!certain_accept)
+	{
+		const float t = near_root_exact(two_a, b, D);
+		if(!accept_distance(t)) return false;
+		lo = hi = t;
+	}
+	return true;
+}
+
 SKR_DEV bool sphere_bracket(f3 o, f3 d, const RayFilt &f, float4 sph, float &lo, float &hi, float &b, float &D)
 {
 	const f3 e = o - ld3(sph);

@@ -69,7 +69,7 @@ void skr_scene::finalize()
 		lights[2 * i] = {l[0], l[1], l[2], 0.0f};
 		lights[2 * i + 1] = {l[3], l[4], l[5], 0.0f};
 	}
-	tris.resize((size_t) nt * 3);
+	tris.assign((size_t) nt * 3 + 3, skr_f4{0.0f, 0.0f, 0.0f, 0.0f}); // + one pad triangle (kernel prefetch)
 	for(int i = 0; i < nt; i++)
 	{
 		const float *t = &raw_triangles[(size_t) i * 9];

@@ -118,7 +118,7 @@ SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float t
 SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second, bool &occ0, bool &occ1)
 {
 	const f3 o = add_scalar(P, 0.000001f);
-	const RayFilt f0 = make_filt(L0), f1 = make_filt(L1);
+	const RayPair rp = make_pair(L0, L1);
 	occ0 = false;
 	occ1 = !second;
 	float4 g_next = sv.geom[0];
@@ -128,9 +128,19 @@ SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second,
 		g_next = sv.geom[i + 1];
 		const f3 e = o - ld3(g);
 		const float c = dot3(e, e) - g.w;
-		float lo, hi, b, D;
-		if(!occ0) occ0 = bracket_from_ec(e, c, L0, f0, lo, hi, b, D);
-		if(!occ1) occ1 = bracket_from_ec(e, c, L1, f1, lo, hi, b, D);
+		f2 b, D;
+		pair_bD(rp, e, c, b, D);
+		// b >= 0 or D < 0 (or NaN): certain miss for that ray
+		const bool cand0 = !occ0 && (D.x >= 0.0f) && (b.x < 0.0f);
+		const bool cand1 = !occ1 && (D.y >= 0.0f) && (b.y < 0.0f);
+		if(cand0 || cand1)
+		{
+			f2 lo, hi;
+			pair_bracket(rp, b, D, lo, hi);
+			float l0 = lo.x, h0 = hi.x, l1 = lo.y, h1 = hi.y;
+			if(cand0) occ0 = bracket_decide(rp.sane0, rp.two_a.x, b.x, D.x, l0, h0);
+			if(cand1) occ1 = bracket_decide(rp.sane1, rp.two_a.y, b.y, D.y, l1, h1);
+		}
 		if(__all(occ0 && occ1)) break;
 	}
 	if(!second) occ1 = false;
