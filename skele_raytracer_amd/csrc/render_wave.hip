@@ -24,6 +24,7 @@
 // schedule differs, so results are bit-identical to the per-pixel kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "shade_common.h"
 
@@ -148,6 +149,7 @@ struct Wave {
 	int lane;
 	int N;            // num_path_traces
 	uint32_t magicN;  // ceil(2^24 / N): t / N == (t * magicN) >> 24 for t < 65536, N <= 256
+	uint32_t magicPP; // the same for pairs per parent, (N+1)/2
 	uint32_t aa;
 	float pdf;
 	int s0_max, s1_max, sbase1; // Cfg<OCC> of this kernel instance
@@ -251,6 +253,148 @@ SKR_DEV void child_round(const Wave &w, const Parent &par, int kbase, int np, in
 	q_push(q, hit, h);
 }
 
+// ---- two sibling rays per lane ------------------------------------------------
+// Children 2j and 2j+1 of a node share their origin (raytrace.h:128), one Philox call
+// (DESIGN.md "RNG") and, per sphere, e = o - C and c = e.e - r^2; the per-ray part runs in
+// packed binary32 (device_math.h RayPair).  Same values as child_round(), half the issue slots.
+struct BestState {
+	int best;
+	float lo, hi, others_lo, b, D;
+};
+
+SKR_DEV void best_update(BestState &s, bool acc, int i, float lo, float hi, float b, float D)
+{
+	if(acc)
+	{
+		if(hi < s.hi)
+		{
+			s.others_lo = __builtin_fminf(s.others_lo, s.lo);
+			s.lo = lo;
+			s.hi = hi;
+			s.best = i;
+			s.b = b;
+			s.D = D;
+		}
+		else s.others_lo = __builtin_fminf(s.others_lo, lo);
+	}
+}
+
+SKR_DEV void best_resolve(const SceneView &sv, f3 o, f3 d, float four_a, BestState &s)
+{
+	if(s.best >= 0 && !(s.others_lo > s.hi))
+	{ // brackets overlap: the exact loop names the winner; recompute its coefficients
+		float tmin;
+		const RayConst r = make_ray(o, d);
+		s.best = closest_sphere_exact(sv, r, tmin);
+		const f3 e = o - ld3(sv.geom[s.best]);
+		s.b = 2 * dot3(d, e);
+		const float c = dot3(e, e) - sv.geom[s.best].w;
+		s.D = s.b * s.b - four_a * c;
+	}
+}
+
+SKR_DEV void closest_pair_deferred(const SceneView &sv, f3 o, f3 d0, f3 d1, bool second, const RayPair &rp, BestState &s0, BestState &s1)
+{
+	s0 = BestState{-1, __builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f, 0.0f};
+	s1 = s0;
+	float4 g_next = sv.geom[0];
+	for(int i = 0; i < sv.ns; i++)
+	{
+		const float4 g = g_next;
+		g_next = sv.geom[i + 1];
+		const f3 e = o - ld3(g);
+		const float c = dot3(e, e) - g.w;
+		f2 b, D;
+		pair_bD(rp, e, c, b, D);
+		const bool cand0 = (D.x >= 0.0f) && (b.x < 0.0f);
+		const bool cand1 = second && (D.y >= 0.0f) && (b.y < 0.0f);
+		if(cand0 || cand1)
+		{
+			f2 lo, hi;
+			pair_bracket(rp, b, D, lo, hi);
+			float l0 = lo.x, h0 = hi.x, l1 = lo.y, h1 = hi.y;
+			const bool acc0 = cand0 && bracket_decide(rp.sane0, rp.two_a.x, b.x, D.x, l0, h0);
+			const bool acc1 = cand1 && bracket_decide(rp.sane1, rp.two_a.y, b.y, D.y, l1, h1);
+			best_update(s0, acc0, i, l0, h0, b.x, D.x);
+			best_update(s1, acc1, i, l1, h1, b.y, D.y);
+		}
+	}
+	best_resolve(sv, o, d0, rp.four_a.x, s0);
+	if(second) best_resolve(sv, o, d1, rp.four_a.y, s1);
+}
+
+struct PairOut {
+	HitRec h0, h1;
+	bool hit0, hit1;
+};
+
+// Finish one traced child: a miss / triangle deposits its term now, a sphere hit fills a record.
+SKR_DEV bool finish_child(const Wave &w, f3 co, f3 d, float two_a, float four_a, const BestState &s, int kl, int i, float r1, int slot, HitRec &h)
+{
+	bool tri = false;
+	if(w.sv.nt > 0)
+	{ // raytrace.h:171-186 needs the sphere's exact t to compare against
+		const float tmin = (s.best >= 0) ? near_root_exact(two_a, s.b, s.D) : __builtin_inff();
+		const RayConst r = RayConst{co, d, two_a, four_a};
+		tri = any_triangle_closer(w.sv, r, tmin);
+	}
+	h.d = d;
+	h.b = s.b;
+	h.D = s.D;
+	h.ids = (uint32_t) (s.best & 0xffff) | ((uint32_t) kl << 16) | ((uint32_t) i << 24);
+	h.slot = slot;
+	h.r1 = r1;
+	if(tri || s.best < 0)
+	{ // raytrace.h:189-192 / :221-224, then :130: total += (r1 * colour) / pdf
+		const f3 colour = tri ? mk3(0, 0, 0) : w.p->background;
+		const f3 contrib = (colour * r1) / w.pdf;
+		float *sl = w.slots + slot;
+		sl[0] = contrib.x;
+		sl[1] = contrib.y;
+		sl[2] = contrib.z;
+		return false;
+	}
+	return true;
+}
+
+// One round of 64 sibling PAIRS (up to 128 child rays) of the parents in lanes [kbase, kbase+np).
+SKR_DEV PairOut child_round_pairs(const Wave &w, const Parent &par, int kbase, int np, int pair0, int sbase, Counters &cn)
+{
+	const int PP = (w.N + 1) >> 1; // pairs per parent
+	const int t = pair0 + w.lane;
+	const bool valid = t < np * PP;
+	const int k = valid ? (int) (((uint32_t) t * w.magicPP) >> 24) : 0;
+	const int j = t - k * PP;
+	const int i0 = 2 * j, i1 = 2 * j + 1;
+	const bool second = valid && i1 < w.N;
+	const int kl = kbase + k;
+	const f3 co = shfl3(par.co, kl), N = shfl3(par.N, kl), nt = shfl3(par.nt, kl), nb = shfl3(par.nb, kl);
+	const uint32_t pixel = (uint32_t) __shfl((int) par.pixel, kl, 64), node = (uint32_t) __shfl((int) par.node, kl, 64);
+	PairOut po;
+	po.hit0 = po.hit1 = false;
+	po.h0.d = po.h1.d = mk3(0, 0, 0);
+	po.h0.b = po.h0.D = po.h0.r1 = po.h1.b = po.h1.D = po.h1.r1 = 0.0f;
+	po.h0.ids = po.h1.ids = 0;
+	po.h0.slot = po.h1.slot = 0;
+	if(valid)
+	{
+		uint32_t rnd[4];
+		philox4x32_10(pixel, w.aa, node, (uint32_t) j, w.p->seed_lo, w.p->seed_hi, rnd);
+		const float r1a = u31_to_unit(rnd[0]), r2a = u31_to_unit(rnd[1]);
+		const float r1b = u31_to_unit(rnd[2]), r2b = u31_to_unit(rnd[3]);
+		const f3 d0 = gi_direction(r1a, r2a, N, nt, nb);
+		const f3 d1 = gi_direction(r1b, r2b, N, nt, nb);
+		cn.rays += second ? 2u : 1u;
+		const RayPair rp = make_pair(d0, d1);
+		BestState s0, s1;
+		closest_pair_deferred(w.sv, co, d0, d1, second, rp, s0, s1);
+		const int slot0 = sbase + k * (3 * w.N + 1) + 3 * i0;
+		po.hit0 = finish_child(w, co, d0, rp.two_a.x, rp.four_a.x, s0, kl, i0, r1a, slot0, po.h0);
+		if(second) po.hit1 = finish_child(w, co, d1, rp.two_a.y, rp.four_a.y, s1, kl, i1, r1b, slot0 + 3, po.h1);
+	}
+	return po;
+}
+
 // Shade m <= 64 queued hits whose node has depth 1 (its own children are shade(depth 0) == 0):
 // raytrace.h:194-213 with indirect = (0,0,0)/N, then the parent's accumulation term (:130).
 SKR_DEV void shade_leaf_batch(const Wave &w, Queue &q, const Parent &par, int m, Counters &cn)
@@ -329,17 +473,22 @@ SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, const Pare
 	for(int w0 = 0; w0 < m; w0 += AW)
 	{
 		const int mw = uni(m - w0 < AW ? m - w0 : AW);
-		const int ntasks = mw * w.N;
-		for(int task0 = 0; task0 < ntasks; task0 += 64)
+		const int npairs = mw * ((w.N + 1) >> 1);
+		for(int pair0 = 0; pair0 < npairs; pair0 += 64)
 		{
-			child_round(w, par1, w0, mw, task0, sbase1, q2, cn);
+			const PairOut po = child_round_pairs(w, par1, w0, mw, pair0, sbase1, cn);
 			STAMP(2);
-			// one call site (code size): full batches as they form, the remainder after the window's last round
-			const bool last = task0 + 64 >= ntasks;
-			while(q2.count >= 64 || (last && q2.count > 0))
-			{
-				shade_leaf_batch(w, q2, par1, q2.count < 64 ? q2.count : 64, cn);
-				STAMP(3);
+			const bool last = pair0 + 64 >= npairs;
+#pragma nounroll
+			for(int sub = 0; sub < 2; sub++)
+			{ // push the even children's hits, drain, then the odd ones: the ring never holds more than 63 + 64
+				q_push(q2, sub ? po.hit1 : po.hit0, sub ? po.h1 : po.h0);
+				// one call site (code size): full batches as they form, the remainder after the window's last round
+				while(q2.count >= 64 || (last && sub == 1 && q2.count > 0))
+				{
+					shade_leaf_batch(w, q2, par1, q2.count < 64 ? q2.count : 64, cn);
+					STAMP(3);
+				}
 			}
 		}
 		wave_lds_fence();
@@ -492,6 +641,10 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 	w.lane = lane;
 	w.N = p.num_path_traces;
 	w.magicN = (uint32_t) (((1u << 24) + (uint32_t) (w.N > 0 ? w.N : 1) - 1u) / (uint32_t) (w.N > 0 ? w.N : 1));
+	{
+		const uint32_t pp = (uint32_t) ((w.N > 0 ? w.N : 1) + 1) >> 1;
+		w.magicPP = ((1u << 24) + pp - 1u) / pp;
+	}
 	w.aa = 0;
 	w.pdf = (float) (1 / 3.14159265358979323846);
 	w.s0_max = C::S0_MAX;
@@ -515,29 +668,31 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 	Counters cn{0, 0, 0};
 	STAMP_DECL;
 	f3 px = mk3(0, 0, 0);
-	if(p.grid_size > 0)
-	{ // main.cpp:140-166
-		const int ns2 = p.grid_size * p.grid_size;
-		for(int s = 0; s < ns2; s++)
+	// main.cpp:140-182: g*g jittered samples (one draw r for both axes, all-float) or one centre
+	// sample (u, v formed in double).  One call site for both (code size).
+	const int nsamp = p.grid_size > 0 ? p.grid_size * p.grid_size : 1;
+	for(int s = 0; s < nsamp; s++)
+	{
+		w.aa = (uint32_t) s;
+		float u, v;
+		if(p.grid_size > 0)
 		{
-			w.aa = (uint32_t) s;
 			uint32_t rnd[4];
 			philox4x32_10(pixel, (uint32_t) s, 0u, 0xFFFFFFFFu, p.seed_lo, p.seed_hi, rnd);
 			const float r = u31_to_unit(rnd[0]);
-			const float u = ((2 * (((float) x + r) * p.inv_width) - 1) * p.angle) * p.aspect;
-			const float v = (1 - 2 * (((float) (int) y + r) * p.inv_height)) * p.angle;
-			const f3 dir = (p.cam_dir + p.cam_right * u) + p.cam_up * v;
-			px = px + shade_tile_sample<DEPTH>(w, valid, p.cam_pos, dir, pixel, q1, q2, lane_tbl, gres, cn STAMP_PASS);
+			u = ((2 * (((float) x + r) * p.inv_width) - 1) * p.angle) * p.aspect;
+			v = (1 - 2 * (((float) (int) y + r) * p.inv_height)) * p.angle;
 		}
-		px = px / (float) ns2;
-	}
-	else
-	{ // main.cpp:168-182
-		const float u = (float) (((2 * (((double) x + 0.5) * (double) p.inv_width) - 1) * (double) p.angle) * (double) p.aspect);
-		const float v = (float) ((1 - 2 * (((double) (int) y + 0.5) * (double) p.inv_height)) * (double) p.angle);
+		else
+		{
+			u = (float) (((2 * (((double) x + 0.5) * (double) p.inv_width) - 1) * (double) p.angle) * (double) p.aspect);
+			v = (float) ((1 - 2 * (((double) (int) y + 0.5) * (double) p.inv_height)) * (double) p.angle);
+		}
 		const f3 dir = (p.cam_dir + p.cam_right * u) + p.cam_up * v;
-		px = shade_tile_sample<DEPTH>(w, valid, p.cam_pos, dir, pixel, q1, q2, lane_tbl, gres, cn STAMP_PASS);
+		const f3 smp = shade_tile_sample<DEPTH>(w, valid, p.cam_pos, dir, pixel, q1, q2, lane_tbl, gres, cn STAMP_PASS);
+		px = (p.grid_size > 0) ? px + smp : smp; // image[y][x] += shade(...) from zero, or = shade(...)
 	}
+	if(p.grid_size > 0) px = px / (float) nsamp;
 
 	if(valid && p.rgbf)
 	{
@@ -598,7 +753,7 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 
 // gillum <= 32: the 3-waves-per-SIMD budget wins (3.6 vs 4.1 ms at N = 16); above, the larger slot
 // windows of the 2-wave budget do (21.9 vs 35 ms at N = 64, 960x540).  Measured: DESIGN.md §6.
-static int wave_occ_for(const RenderParams &p) { return (p.monte_carlo && p.num_path_traces > 32) ? 2 : 3; }
+static int wave_occ_for(const RenderParams &p) { const char *e = getenv("SKR_OCC"); if(e) return atoi(e); return (p.monte_carlo && p.num_path_traces > 32) ? 2 : 3; }
 
 size_t skr_wave_lds_bytes(const RenderParams &p)
 {

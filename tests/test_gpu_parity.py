@@ -68,6 +68,11 @@ CASES = [
     ("test_mixed_shadow", "test.scn", 160, 120, dict(shadow=True)),
     ("bear_shadow", "bear.scn", 160, 120, dict(shadow=True)),
     ("bear_gi8", "bear.scn", 96, 72, dict(gillum=8, shadow=True, seed=9)),
+    ("spheres2_gi64", "spheres2.scn", 48, 27, dict(gillum=64, shadow=True, seed=6)),        # large-gillum LDS budget (Cfg<2>)
+    ("spheres2_gi33_d2", "spheres2.scn", 64, 36, dict(gillum=33, depth=2, shadow=True, seed=2)),
+    ("spheres2_gi256_d2", "spheres2.scn", 24, 14, dict(gillum=256, depth=2, seed=2)),          # largest gillum the streaming kernel takes
+    ("spheres2_gi300_d2", "spheres2.scn", 16, 9, dict(gillum=300, depth=2, seed=2)),           # beyond it: per-pixel kernel
+    ("spheres1_gi7_js2", "spheres1.scn", 64, 36, dict(gillum=7, jsample=2, shadow=True, seed=21)),
     ("tiny_1x1", "spheres2.scn", 1, 1, dict(gillum=4, shadow=True)),
     ("tall_3x70", "spheres1.scn", 3, 70, dict(jsample=2, shadow=True)),
 ]
