@@ -137,7 +137,8 @@ SKR_DEV void q_drop(Queue &q, int m)
 // A tree node whose children are being traced, held in the registers of one lane.
 struct Parent {
 	f3 co;          // child ray origin: P + 0.00001f (raytrace.h:128)
-	f3 N, nt, nb;   // normal and the tangent basis of utils.h:148-165
+	f3 N;           // normal; the tangent basis of utils.h:148-165 is re-formed from it per round
+	                // (same float operations, so the same basis) instead of occupying 6 more VGPRs
 	uint32_t pixel; // RNG key: global pixel index
 	uint32_t node;  // RNG key: this node's id (root 0, child c of n = n*N + c + 1)
 };
@@ -205,7 +206,9 @@ SKR_DEV void child_round(const Wave &w, const Parent &par, int kbase, int np, in
 	const int k = valid ? (int) (((uint32_t) t * w.magicN) >> 24) : 0; // parent within the window [kbase, kbase+np)
 	const int i = t - k * w.N;
 	const int kl = kbase + k;                                           // lane that holds the parent
-	const f3 co = shfl3(par.co, kl), N = shfl3(par.N, kl), nt = shfl3(par.nt, kl), nb = shfl3(par.nb, kl);
+	const f3 co = shfl3(par.co, kl), N = shfl3(par.N, kl);
+	f3 nt, nb;
+	tangent_basis(N, nt, nb);
 	const uint32_t pixel = (uint32_t) __shfl((int) par.pixel, kl, 64), node = (uint32_t) __shfl((int) par.node, kl, 64);
 	HitRec h;
 	h.d = mk3(0, 0, 0);
@@ -368,7 +371,9 @@ SKR_DEV PairOut child_round_pairs(const Wave &w, const Parent &par, int kbase, i
 	const int i0 = 2 * j, i1 = 2 * j + 1;
 	const bool second = valid && i1 < w.N;
 	const int kl = kbase + k;
-	const f3 co = shfl3(par.co, kl), N = shfl3(par.N, kl), nt = shfl3(par.nt, kl), nb = shfl3(par.nb, kl);
+	const f3 co = shfl3(par.co, kl), N = shfl3(par.N, kl);
+	f3 nt, nb;
+	tangent_basis(N, nt, nb);
 	const uint32_t pixel = (uint32_t) __shfl((int) par.pixel, kl, 64), node = (uint32_t) __shfl((int) par.node, kl, 64);
 	PairOut po;
 	po.hit0 = po.hit1 = false;
@@ -448,7 +453,7 @@ SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, const Pare
 	const uint32_t pixel = (uint32_t) __shfl((int) par0.pixel, act ? k0 : 0, 64);
 	q_drop(q1, m);
 	Parent par1;
-	par1.co = par1.N = par1.nt = par1.nb = mk3(0, 0, 0);
+	par1.co = par1.N = mk3(0, 0, 1);
 	par1.pixel = pixel;
 	par1.node = ((h.ids >> 24) & 0xffu) + 1u; // child i of the root (node 0): 0*N + i + 1
 	f3 direct1 = mk3(0, 0, 0);
@@ -462,7 +467,6 @@ SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, const Pare
 		par1.N = normalize3(P - ld3(w.sv.geom[sph1]));
 		cn.hits++;
 		direct1 = direct_light(w.sv, *w.p, sph1, P, par1.N, cn);
-		tangent_basis(par1.N, par1.nt, par1.nb);
 		par1.co = add_scalar(P, 0.00001f);
 	}
 	const int sbase1 = w.sbase1;
@@ -519,7 +523,7 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 	int sph0 = 0;
 	f3 direct0 = mk3(0, 0, 0);
 	Parent mine;
-	mine.co = mine.N = mine.nt = mine.nb = mk3(0, 0, 0);
+	mine.co = mine.N = mk3(0, 0, 1);
 	mine.pixel = pixel;
 	mine.node = 0;
 	if(valid)
@@ -539,11 +543,7 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 			mine.N = normalize3(P - ld3(w.sv.geom[sph]));
 			direct0 = direct_light(w.sv, p, sph, P, mine.N, cn);
 			result = direct0;
-			if(DEPTH > 1 && p.monte_carlo)
-			{
-				tangent_basis(mine.N, mine.nt, mine.nb);
-				mine.co = add_scalar(P, 0.00001f);
-			}
+			if(DEPTH > 1 && p.monte_carlo) mine.co = add_scalar(P, 0.00001f);
 		}
 	}
 	STAMP(0);
@@ -567,8 +567,6 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 			Parent par0;
 			par0.co = shfl3(mine.co, src);
 			par0.N = shfl3(mine.N, src);
-			par0.nt = shfl3(mine.nt, src);
-			par0.nb = shfl3(mine.nb, src);
 			par0.pixel = (uint32_t) __shfl((int) mine.pixel, src, 64);
 			par0.node = 0;
 			const int ntasks = gp * w.N;
