@@ -36,11 +36,13 @@ namespace {
 constexpr int QF = 8;        // dwords per queue record: d.xyz, b, D, packed ids, slot, r1
 constexpr int PAR_MAX = 32;  // parents per group / per leaf-slot window (G, AW <= PAR_MAX)
 constexpr int Q1_CAP = 128;  // level-1 hits waiting to become parents: <= 63 + 64 entries
-constexpr int Q2_CAP = 128;  // leaf hits waiting to be shaded: <= 63 + 64 entries
 template <int OCC>
 struct Cfg {
 	static constexpr int S0_MAX = (OCC >= 3) ? 128 : 256; // level-1 contribution slots of one parent group (G * N <= S0_MAX)
 	static constexpr int S1_MAX = (OCC >= 3) ? 256 : 512; // leaf contribution slots of one window          (AW * N <= S1_MAX)
+	// leaf hits waiting to be shaded: <= 63 left over + the 128 a pair round can add (or 64 at a time
+	// with a drain in between when the ring is small)
+	static constexpr int Q2_CAP = (OCC >= 3) ? 128 : 192;
 	static constexpr int REGION0_FLOATS = S0_MAX * 3 + PAR_MAX; // + one pad dword per parent (bank spread)
 	static constexpr int REGION1_FLOATS = S1_MAX * 3 + PAR_MAX;
 	static constexpr int SLOT_FLOATS = REGION0_FLOATS + REGION1_FLOATS;
@@ -154,6 +156,7 @@ struct Wave {
 	uint32_t aa;
 	float pdf;
 	int s0_max, s1_max, sbase1; // Cfg<OCC> of this kernel instance
+	bool q2_two_step;           // the leaf ring cannot take both halves of a pair round at once
 };
 
 // closest accepted sphere without forming the winner's exact t2 (done later, in the
@@ -483,12 +486,25 @@ SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, const Pare
 			const PairOut po = child_round_pairs(w, par1, w0, mw, pair0, sbase1, cn);
 			STAMP(2);
 			const bool last = pair0 + 64 >= npairs;
+			if(w.q2_two_step)
+			{ // small ring: push the even children's hits, drain, then the odd ones (never more than 63 + 64 queued)
 #pragma nounroll
-			for(int sub = 0; sub < 2; sub++)
-			{ // push the even children's hits, drain, then the odd ones: the ring never holds more than 63 + 64
-				q_push(q2, sub ? po.hit1 : po.hit0, sub ? po.h1 : po.h0);
+				for(int sub = 0; sub < 2; sub++)
+				{
+					q_push(q2, sub ? po.hit1 : po.hit0, sub ? po.h1 : po.h0);
+					while(q2.count >= 64 || (last && sub == 1 && q2.count > 0))
+					{
+						shade_leaf_batch(w, q2, par1, q2.count < 64 ? q2.count : 64, cn);
+						STAMP(3);
+					}
+				}
+			}
+			else
+			{
+				q_push(q2, po.hit0, po.h0);
+				q_push(q2, po.hit1, po.h1);
 				// one call site (code size): full batches as they form, the remainder after the window's last round
-				while(q2.count >= 64 || (last && sub == 1 && q2.count > 0))
+				while(q2.count >= 64 || (last && q2.count > 0))
 				{
 					shade_leaf_batch(w, q2, par1, q2.count < 64 ? q2.count : 64, cn);
 					STAMP(3);
@@ -648,7 +664,8 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 	w.s0_max = C::S0_MAX;
 	w.s1_max = C::S1_MAX;
 	w.sbase1 = C::REGION0_FLOATS;
-	Queue q1{wbase + C::SLOT_FLOATS, Q1_CAP, 0, 0}, q2{wbase + C::SLOT_FLOATS + Q1_CAP * QF, Q2_CAP, 0, 0};
+	w.q2_two_step = C::Q2_CAP < 63 + 128;
+	Queue q1{wbase + C::SLOT_FLOATS, Q1_CAP, 0, 0}, q2{wbase + C::SLOT_FLOATS + Q1_CAP * QF, C::Q2_CAP, 0, 0};
 	int *lane_tbl = reinterpret_cast<int *>(wbase + C::REGION0_FLOATS); // aliases of the leaf slot region, see Cfg
 	float *gres = wbase + C::REGION0_FLOATS + 64;
 	unsigned char *s_tile = reinterpret_cast<unsigned char *>(gres + PAR_MAX * 3);
@@ -780,7 +797,9 @@ hipError_t skr_launch_wave(const RenderParams &p, hipStream_t stream)
 	const dim3 grid((p.width + 15) / 16, (p.out_rows + 15) / 16);
 	const size_t lds = skr_wave_lds_bytes(p);
 	const bool occ3 = wave_occ_for(p) == 3;
-	switch(p.max_depth)
+	// without --gillum shade() never recurses (raytrace.h:208-218), and without spheres nothing is ever
+	// hit that would: every depth is then the depth-1 instance
+	switch((p.monte_carlo && p.n_spheres > 0) ? p.max_depth : 1)
 	{
 		case 1: return launch_wave_depth<1, 3>(p, grid, lds, stream);
 		case 2: return occ3 ? launch_wave_depth<2, 3>(p, grid, lds, stream) : launch_wave_depth<2, 2>(p, grid, lds, stream);

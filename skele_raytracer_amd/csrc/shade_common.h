@@ -180,10 +180,13 @@ SKR_DEV f3 direct_light(const SceneView &sv, const RenderParams &p, int sph, f3 
 			cn.shadow_rays += second ? 2u : 1u;
 			occluded_pair(sv, P, t0.L, t1.L, second, occ0, occ1);
 		}
-#pragma unroll
+#pragma nounroll
 		for(int k = 0; k < 2; k++)
-		{
-			const LightTerm &t = k ? t1 : t0;
+		{ // not unrolled: two interleaved binary64 pow evaluations would double the live registers
+			LightTerm t;
+			t.L = k ? t1.L : t0.L;
+			t.lc = k ? t1.lc : t0.lc;
+			t.len = k ? t1.len : t0.len;
 			const bool lit = k ? (second && !occ1) : !occ0;
 			if(lit)
 			{
