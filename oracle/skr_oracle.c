@@ -163,7 +163,8 @@ void sko_sincos_shared(float phi, float *s, float *c)
 }
 
 /* powf(x, p) for x >= 0 (x is max(0, N.H), blinn_phong.h:117), evaluated in
- * binary64 as 2^(p*log2 x) and rounded once. */
+ * binary64 and rounded once: by square-and-multiply for integer p in [1,1024],
+ * as 2^(p*log2 x) otherwise. */
 float sko_powf_shared(float x, float p)
 {
 	if(p == 0.0f) return 1.0f;
@@ -172,6 +173,18 @@ float sko_powf_shared(float x, float p)
 	if(x == 1.0f) return 1.0f;
 	if(x == INFINITY) return (p > 0.0f) ? INFINITY : 0.0f;
 	if(x < 0.0f) return NAN;
+	if(p >= 1.0f && p <= 1024.0f && p == rintf(p))
+	{ /* integer phong exponents (every shipped scene): square-and-multiply in binary64, low bit first */
+		unsigned n = (unsigned) p;
+		double r = 1.0, base = (double) x;
+		while(n)
+		{
+			if(n & 1u) r *= base;
+			n >>= 1;
+			if(n) base *= base;
+		}
+		return (float) r;
+	}
 	uint64_t b = as_u64((double) x);
 	int e = (int) ((b >> 52) & 0x7ff) - 1023;
 	double m = as_double((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull);

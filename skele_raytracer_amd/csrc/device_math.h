@@ -102,15 +102,11 @@ SKR_DEV void sincos_spec(float phi, float &s, float &c)
 	c = (float) cv;
 }
 
-// powf(x, p), x >= 0, as 2^(p log2 x) in binary64, rounded once.
-SKR_DEV float powf_spec(float x, float p)
+// General (non-integer exponent) branch of powf_spec: 2^(p log2 x) in binary64.  Cold for every
+// shipped scene, so it is kept out of line: inlined, its two dozen binary64 constants and
+// temporaries raise the register pressure of every shading path.
+static __device__ __attribute__((noinline)) float powf_general(float x, float p)
 {
-	if(p == 0.0f) return 1.0f;
-	if(x != x || p != p) return x + p;
-	if(x == 0.0f) return (p > 0.0f) ? 0.0f : __builtin_inff();
-	if(x == 1.0f) return 1.0f;
-	if(x == __builtin_inff()) return (p > 0.0f) ? __builtin_inff() : 0.0f;
-	if(x < 0.0f) return __builtin_nanf("");
 	const uint64_t b = (uint64_t) __double_as_longlong((double) x);
 	int e = (int) ((b >> 52) & 0x7ff) - 1023;
 	double m = __longlong_as_double((long long) ((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull));
@@ -155,6 +151,31 @@ SKR_DEV float powf_spec(float x, float p)
 	r = fma(r, t, 1.0);
 	const double scale = __longlong_as_double((long long) ((uint64_t) ((int) n + 1023) << 52));
 	return (float) (r * scale);
+}
+
+// powf(x, p), x >= 0, in binary64, rounded once: square-and-multiply for integer p in [1,1024],
+// 2^(p log2 x) otherwise.
+SKR_DEV float powf_spec(float x, float p)
+{
+	if(p == 0.0f) return 1.0f;
+	if(x != x || p != p) return x + p;
+	if(x == 0.0f) return (p > 0.0f) ? 0.0f : __builtin_inff();
+	if(x == 1.0f) return 1.0f;
+	if(x == __builtin_inff()) return (p > 0.0f) ? __builtin_inff() : 0.0f;
+	if(x < 0.0f) return __builtin_nanf("");
+	if(p >= 1.0f && p <= 1024.0f && p == __builtin_rintf(p))
+	{ // integer phong exponents (every shipped scene): square-and-multiply in binary64, low bit first
+		unsigned n = (unsigned) p;
+		double r = 1.0, base = (double) x;
+		while(n)
+		{
+			if(n & 1u) r *= base;
+			n >>= 1;
+			if(n) base *= base;
+		}
+		return (float) r;
+	}
+	return powf_general(x, p);
 }
 
 // ---------------------------------------------------------- geometry ----
