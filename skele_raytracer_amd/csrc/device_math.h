@@ -70,6 +70,8 @@ SKR_DEV float u31_to_unit(uint32_t w) { return (float) (w >> 1) * 4.656612873077
 
 // ------------------------------------------------------- shared math ----
 // sin/cos of a binary32 angle evaluated in binary64, rounded once.
+// Its only caller, gi_direction(), is kept out of line: inlined, the binary64 polynomial constants stay
+// live across the callers' loops and cost ~40 VGPRs of pressure everywhere.
 SKR_DEV void sincos_spec(float phi, float &s, float &c)
 {
 	const double x = (double) phi;

@@ -34,8 +34,6 @@ namespace {
 //   Cfg<3>: 12.5 KB of LDS per wave, <= 168 VGPRs  — best for gillum <= 32 (more waves hide latency)
 //   Cfg<2>: 17.5 KB of LDS per wave, <= 256 VGPRs  — bigger slot windows, best for large gillum
 constexpr int QF = 8;        // dwords per queue record: d.xyz, b, D, packed ids, slot, r1
-constexpr int PAR_MAX = 32;  // parents per group / per leaf-slot window (G, AW <= PAR_MAX)
-constexpr int Q1_CAP = 128;  // level-1 hits waiting to become parents: <= 63 + 64 entries
 template <int OCC>
 struct Cfg {
 	static constexpr int S0_MAX = (OCC >= 3) ? 128 : 256; // level-1 contribution slots of one parent group (G * N <= S0_MAX)
@@ -43,12 +41,19 @@ struct Cfg {
 	// leaf hits waiting to be shaded: <= 63 left over + the 128 a pair round can add (or 64 at a time
 	// with a drain in between when the ring is small)
 	static constexpr int Q2_CAP = (OCC >= 3) ? 128 : 192;
-	static constexpr int REGION0_FLOATS = S0_MAX * 3 + PAR_MAX; // + one pad dword per parent (bank spread)
-	static constexpr int REGION1_FLOATS = S1_MAX * 3 + PAR_MAX;
+	// level-1 hits are turned into parents ACT_MAX at a time; the ring holds <= ACT_MAX-1 left over + 64 new
+	static constexpr int ACT_MAX = (OCC >= 3) ? 56 : 64;
+	static constexpr int Q1_CAP = ACT_MAX + 64;
+	static constexpr int PAR0_MAX = (OCC >= 3) ? 8 : 16;  // level-1 parents per group (G)
+	static constexpr int REGION0_FLOATS = S0_MAX * 3 + PAR0_MAX; // + one pad dword per parent (bank spread)
+	static constexpr int AW_MAX = (OCC >= 3) ? 16 : 32;          // parents per leaf-slot window
+	static constexpr int REGION1_FLOATS = S1_MAX * 3 + AW_MAX;
 	static constexpr int SLOT_FLOATS = REGION0_FLOATS + REGION1_FLOATS;
 	// the parent-lane table, the group results and the 8x8 u8 tile alias the (then idle) leaf slot region
-	static constexpr int WAVE_LDS_FLOATS = SLOT_FLOATS + (Q1_CAP + Q2_CAP) * QF;
-	static_assert(REGION1_FLOATS >= 64 + PAR_MAX * 3 + 48, "aliases must fit");
+	// level-1 parents of the current group live in LDS (8 dwords each), not in registers: they are only
+	// touched once per round, and holding them in VGPRs through the leaf phases cost occupancy
+	static constexpr int WAVE_LDS_FLOATS = SLOT_FLOATS + (Q1_CAP + Q2_CAP) * QF + PAR0_MAX * 8;
+	static_assert(REGION1_FLOATS >= 64 + PAR0_MAX * 3 + 48, "aliases must fit");
 };
 constexpr int GILLUM_MAX = 256; // child index is 8 bits in HitRec.ids; Cfg<2>::S0_MAX
 
@@ -155,9 +160,42 @@ struct Wave {
 	uint32_t magicPP; // the same for pairs per parent, (N+1)/2
 	uint32_t aa;
 	float pdf;
-	int s0_max, s1_max, sbase1; // Cfg<OCC> of this kernel instance
+	int s0_max, s1_max, sbase1, par0_max, aw_max, act_max; // Cfg<OCC> of this kernel instance
+	const float *par0_tbl;                // level-1 parents of the current group: co.xyz, N.xyz, pixel, -
 	bool q2_two_step;           // the leaf ring cannot take both halves of a pair round at once
 };
+
+// Where a round's parents live: registers of lanes (shuffle) or the wave's LDS table.
+struct ParSrc {
+	const Parent *regs; // nullptr => LDS table
+	const float *tbl;
+};
+
+SKR_DEV void fetch_parent(const ParSrc &s, int kl, f3 &co, f3 &N, uint32_t &pixel, uint32_t &node)
+{
+	if(s.regs)
+	{
+		co = shfl3(s.regs->co, kl);
+		N = shfl3(s.regs->N, kl);
+		pixel = (uint32_t) __shfl((int) s.regs->pixel, kl, 64);
+		node = (uint32_t) __shfl((int) s.regs->node, kl, 64);
+	}
+	else
+	{
+		const float *r = s.tbl + 8 * kl;
+		co = mk3(r[0], r[1], r[2]);
+		N = mk3(r[3], r[4], r[5]);
+		pixel = __float_as_uint(r[6]);
+		node = 0; // level-1 parents are the primary hits: tree root
+	}
+}
+
+SKR_DEV f3 fetch_parent_origin(const ParSrc &s, int kl)
+{
+	if(s.regs) return shfl3(s.regs->co, kl);
+	const float *r = s.tbl + 8 * kl;
+	return mk3(r[0], r[1], r[2]);
+}
 
 // closest accepted sphere without forming the winner's exact t2 (done later, in the
 // compacted shading pass): returns the sphere and its float coefficients b, D.
@@ -202,17 +240,17 @@ SKR_DEV int closest_sphere_deferred(const SceneView &sv, f3 o, f3 d, const RayFi
 
 // One round of child rays: lane = task task0 + lane = (parent k, child i) of the parents
 // held in lanes [kbase, kbase+np).  The contribution slot of (k, i) is slots[sbase + k*(3N+1) + 3i].
-SKR_DEV void child_round(const Wave &w, const Parent &par, int kbase, int np, int task0, int sbase, Queue &q, Counters &cn)
+SKR_DEV void child_round(const Wave &w, const ParSrc &par, int kbase, int np, int task0, int sbase, Queue &q, Counters &cn)
 {
 	const int t = task0 + w.lane;
 	const bool valid = t < np * w.N;
 	const int k = valid ? (int) (((uint32_t) t * w.magicN) >> 24) : 0; // parent within the window [kbase, kbase+np)
 	const int i = t - k * w.N;
 	const int kl = kbase + k;                                           // lane that holds the parent
-	const f3 co = shfl3(par.co, kl), N = shfl3(par.N, kl);
-	f3 nt, nb;
+	f3 co, N, nt, nb;
+	uint32_t pixel, node;
+	fetch_parent(par, kl, co, N, pixel, node);
 	tangent_basis(N, nt, nb);
-	const uint32_t pixel = (uint32_t) __shfl((int) par.pixel, kl, 64), node = (uint32_t) __shfl((int) par.node, kl, 64);
 	HitRec h;
 	h.d = mk3(0, 0, 0);
 	h.b = h.D = h.r1 = 0.0f;
@@ -364,7 +402,7 @@ SKR_DEV bool finish_child(const Wave &w, f3 co, f3 d, float two_a, float four_a,
 }
 
 // One round of 64 sibling PAIRS (up to 128 child rays) of the parents in lanes [kbase, kbase+np).
-SKR_DEV PairOut child_round_pairs(const Wave &w, const Parent &par, int kbase, int np, int pair0, int sbase, Counters &cn)
+SKR_DEV PairOut child_round_pairs(const Wave &w, const ParSrc &par, int kbase, int np, int pair0, int sbase, Counters &cn)
 {
 	const int PP = (w.N + 1) >> 1; // pairs per parent
 	const int t = pair0 + w.lane;
@@ -374,10 +412,10 @@ SKR_DEV PairOut child_round_pairs(const Wave &w, const Parent &par, int kbase, i
 	const int i0 = 2 * j, i1 = 2 * j + 1;
 	const bool second = valid && i1 < w.N;
 	const int kl = kbase + k;
-	const f3 co = shfl3(par.co, kl), N = shfl3(par.N, kl);
-	f3 nt, nb;
+	f3 co, N, nt, nb;
+	uint32_t pixel, node;
+	fetch_parent(par, kl, co, N, pixel, node);
 	tangent_basis(N, nt, nb);
-	const uint32_t pixel = (uint32_t) __shfl((int) par.pixel, kl, 64), node = (uint32_t) __shfl((int) par.node, kl, 64);
 	PairOut po;
 	po.hit0 = po.hit1 = false;
 	po.h0.d = po.h1.d = mk3(0, 0, 0);
@@ -405,13 +443,13 @@ SKR_DEV PairOut child_round_pairs(const Wave &w, const Parent &par, int kbase, i
 
 // Shade m <= 64 queued hits whose node has depth 1 (its own children are shade(depth 0) == 0):
 // raytrace.h:194-213 with indirect = (0,0,0)/N, then the parent's accumulation term (:130).
-SKR_DEV void shade_leaf_batch(const Wave &w, Queue &q, const Parent &par, int m, Counters &cn)
+SKR_DEV void shade_leaf_batch(const Wave &w, Queue &q, const ParSrc &par, int m, Counters &cn)
 {
 	wave_lds_fence();
 	const bool act = w.lane < m;
 	HitRec h = q_read(q, act ? w.lane : 0);
 	const int k = (int) ((h.ids >> 16) & 0xffu);
-	const f3 co = shfl3(par.co, act ? k : 0);
+	const f3 co = fetch_parent_origin(par, act ? k : 0);
 	if(act)
 	{
 		const int sph = (int) (h.ids & 0xffffu);
@@ -445,15 +483,16 @@ SKR_DEV f3 sum_slots(const Wave &w, int sbase, int k)
 // DEPTH == 3: m <= 64 queued level-1 hits become the active parents (lanes [0,m)); their
 // N leaf rays each are traced in rounds, leaf hits are shaded in batches of 64, and each
 // parent's result is deposited in ITS parent's slot (raytrace.h:130).
-SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, const Parent &par0, int m, Counters &cn STAMP_ARG)
+SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, int m, Counters &cn STAMP_ARG)
 {
 	STAMP(1);
 	wave_lds_fence();
 	const bool act = w.lane < m;
 	const HitRec h = q_read(q1, act ? w.lane : 0);
 	const int k0 = (int) ((h.ids >> 16) & 0xffu);
-	const f3 co0 = shfl3(par0.co, act ? k0 : 0);
-	const uint32_t pixel = (uint32_t) __shfl((int) par0.pixel, act ? k0 : 0, 64);
+	const float *p0 = w.par0_tbl + 8 * (act ? k0 : 0);
+	const f3 co0 = mk3(p0[0], p0[1], p0[2]);
+	const uint32_t pixel = __float_as_uint(p0[6]);
 	q_drop(q1, m);
 	Parent par1;
 	par1.co = par1.N = mk3(0, 0, 1);
@@ -473,17 +512,18 @@ SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, const Pare
 		par1.co = add_scalar(P, 0.00001f);
 	}
 	const int sbase1 = w.sbase1;
+	const ParSrc src1{&par1, nullptr};
 	STAMP(4);
 	// the m parents were shaded together (full-width); their leaf rays go through the slot area a
 	// window of AW parents at a time
-	const int AW = uni(w.s1_max / w.N < PAR_MAX ? w.s1_max / w.N : PAR_MAX);
+	const int AW = uni(w.s1_max / w.N < w.aw_max ? w.s1_max / w.N : w.aw_max);
 	for(int w0 = 0; w0 < m; w0 += AW)
 	{
 		const int mw = uni(m - w0 < AW ? m - w0 : AW);
 		const int npairs = mw * ((w.N + 1) >> 1);
 		for(int pair0 = 0; pair0 < npairs; pair0 += 64)
 		{
-			const PairOut po = child_round_pairs(w, par1, w0, mw, pair0, sbase1, cn);
+			const PairOut po = child_round_pairs(w, src1, w0, mw, pair0, sbase1, cn);
 			STAMP(2);
 			const bool last = pair0 + 64 >= npairs;
 			if(w.q2_two_step)
@@ -494,7 +534,7 @@ SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, const Pare
 					q_push(q2, sub ? po.hit1 : po.hit0, sub ? po.h1 : po.h0);
 					while(q2.count >= 64 || (last && sub == 1 && q2.count > 0))
 					{
-						shade_leaf_batch(w, q2, par1, q2.count < 64 ? q2.count : 64, cn);
+						shade_leaf_batch(w, q2, src1, q2.count < 64 ? q2.count : 64, cn);
 						STAMP(3);
 					}
 				}
@@ -506,7 +546,7 @@ SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, const Pare
 				// one call site (code size): full batches as they form, the remainder after the window's last round
 				while(q2.count >= 64 || (last && q2.count > 0))
 				{
-					shade_leaf_batch(w, q2, par1, q2.count < 64 ? q2.count : 64, cn);
+					shade_leaf_batch(w, q2, src1, q2.count < 64 ? q2.count : 64, cn);
 					STAMP(3);
 				}
 			}
@@ -537,7 +577,6 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 	f3 result = mk3(0, 0, 0);
 	bool hit = false;
 	int sph0 = 0;
-	f3 direct0 = mk3(0, 0, 0);
 	Parent mine;
 	mine.co = mine.N = mk3(0, 0, 1);
 	mine.pixel = pixel;
@@ -557,8 +596,7 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 			cn.hits++;
 			const f3 P = o + d * tmin;
 			mine.N = normalize3(P - ld3(w.sv.geom[sph]));
-			direct0 = direct_light(w.sv, p, sph, P, mine.N, cn);
-			result = direct0;
+			result = direct_light(w.sv, p, sph, P, mine.N, cn); // direct colour; combined with the indirect term below
 			if(DEPTH > 1 && p.monte_carlo) mine.co = add_scalar(P, 0.00001f);
 		}
 	}
@@ -571,7 +609,8 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 		const unsigned long long M0 = __ballot(hit);
 		const int n0 = (int) __popcll(M0);
 		const int rank = lanes_below(M0);
-		const int G = uni(w.s0_max / (w.N > 0 ? w.N : 1) < PAR_MAX ? w.s0_max / (w.N > 0 ? w.N : 1) : PAR_MAX);
+		const int G = uni(w.s0_max / (w.N > 0 ? w.N : 1) < w.par0_max ? w.s0_max / (w.N > 0 ? w.N : 1) : w.par0_max);
+		const ParSrc src0{nullptr, w.par0_tbl};
 		for(int g0 = 0; g0 < n0 && w.N > 0; g0 += G)
 		{
 			const int gp = uni(n0 - g0 < G ? n0 - g0 : G);
@@ -580,25 +619,32 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 			if(in_group) lane_tbl[rank - g0] = w.lane;
 			wave_lds_fence();
 			const int src = (w.lane < gp) ? lane_tbl[w.lane] : 0;
-			Parent par0;
-			par0.co = shfl3(mine.co, src);
-			par0.N = shfl3(mine.N, src);
-			par0.pixel = (uint32_t) __shfl((int) mine.pixel, src, 64);
-			par0.node = 0;
+			{ // the group's parents go to the LDS table: co.xyz, N.xyz, pixel
+				const f3 pco = shfl3(mine.co, src), pN = shfl3(mine.N, src);
+				const uint32_t ppix = (uint32_t) __shfl((int) mine.pixel, src, 64);
+				if(w.lane < gp)
+				{
+					float *r = const_cast<float *>(w.par0_tbl) + 8 * w.lane;
+					r[0] = pco.x; r[1] = pco.y; r[2] = pco.z;
+					r[3] = pN.x;  r[4] = pN.y;  r[5] = pN.z;
+					r[6] = __uint_as_float(ppix);
+				}
+				wave_lds_fence();
+			}
 			const int ntasks = gp * w.N;
 			for(int task0 = 0; task0 < ntasks; task0 += 64)
 			{
 				const bool last = task0 + 64 >= ntasks;
 				if constexpr(DEPTH == 2)
 				{
-					child_round(w, par0, 0, gp, task0, 0, q2, cn);
-					while(q2.count >= 64 || (last && q2.count > 0)) shade_leaf_batch(w, q2, par0, q2.count < 64 ? q2.count : 64, cn);
+					child_round(w, src0, 0, gp, task0, 0, q2, cn);
+					while(q2.count >= 64 || (last && q2.count > 0)) shade_leaf_batch(w, q2, src0, q2.count < 64 ? q2.count : 64, cn);
 				}
 				else
 				{
-					child_round(w, par0, 0, gp, task0, 0, q1, cn);
+					child_round(w, src0, 0, gp, task0, 0, q1, cn);
 					STAMP(1);
-					while(q1.count >= 64 || (last && q1.count > 0)) expand_level1_batch(w, q1, q2, par0, q1.count < 64 ? q1.count : 64, cn STAMP_PASS);
+					while(q1.count >= w.act_max || (last && q1.count > 0)) expand_level1_batch(w, q1, q2, q1.count < w.act_max ? q1.count : w.act_max, cn STAMP_PASS);
 				}
 			}
 			wave_lds_fence();
@@ -617,7 +663,7 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 	if(hit)
 	{ // raytrace.h:133 + :213
 		const f3 total = indirect / (float) w.N;
-		result = (direct0 / (float) 3.14159265358979323846 + total * 2.0f) * ld3(w.sv.kd[sph0]);
+		result = (result / (float) 3.14159265358979323846 + total * 2.0f) * ld3(w.sv.kd[sph0]);
 	}
 	return result;
 }
@@ -665,10 +711,14 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 	w.s1_max = C::S1_MAX;
 	w.sbase1 = C::REGION0_FLOATS;
 	w.q2_two_step = C::Q2_CAP < 63 + 128;
-	Queue q1{wbase + C::SLOT_FLOATS, Q1_CAP, 0, 0}, q2{wbase + C::SLOT_FLOATS + Q1_CAP * QF, C::Q2_CAP, 0, 0};
+	w.par0_max = C::PAR0_MAX;
+	w.aw_max = C::AW_MAX;
+	w.act_max = C::ACT_MAX;
+	w.par0_tbl = wbase + C::SLOT_FLOATS + (C::Q1_CAP + C::Q2_CAP) * QF;
+	Queue q1{wbase + C::SLOT_FLOATS, C::Q1_CAP, 0, 0}, q2{wbase + C::SLOT_FLOATS + C::Q1_CAP * QF, C::Q2_CAP, 0, 0};
 	int *lane_tbl = reinterpret_cast<int *>(wbase + C::REGION0_FLOATS); // aliases of the leaf slot region, see Cfg
 	float *gres = wbase + C::REGION0_FLOATS + 64;
-	unsigned char *s_tile = reinterpret_cast<unsigned char *>(gres + PAR_MAX * 3);
+	unsigned char *s_tile = reinterpret_cast<unsigned char *>(gres + C::PAR0_MAX * 3);
 
 	const int lx = lane & 7, ly = lane >> 3;
 	const int x0 = (blockIdx.x * 2 + (wave & 1)) * 8;
@@ -768,13 +818,30 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 
 // gillum <= 32: the 3-waves-per-SIMD budget wins (3.6 vs 4.1 ms at N = 16); above, the larger slot
 // windows of the 2-wave budget do (21.9 vs 35 ms at N = 64, 960x540).  Measured: DESIGN.md §6.
-static int wave_occ_for(const RenderParams &p) { const char *e = getenv("SKR_OCC"); if(e) return atoi(e); return (p.monte_carlo && p.num_path_traces > 32) ? 2 : 3; }
-
-size_t skr_wave_lds_bytes(const RenderParams &p)
+static size_t wave_block_lds(const RenderParams &p, int occ)
 {
-	const size_t per_wave = (wave_occ_for(p) == 3 ? Cfg<3>::WAVE_LDS_FLOATS : Cfg<2>::WAVE_LDS_FLOATS) * sizeof(float);
+	const size_t per_wave = (occ == 3 ? Cfg<3>::WAVE_LDS_FLOATS : Cfg<2>::WAVE_LDS_FLOATS) * sizeof(float);
 	return ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 4 * per_wave;
 }
+
+// Which LDS/VGPR budget to launch.  gillum <= 32: three waves per SIMD win (3.1 vs 3.6 ms at N = 16);
+// above, the larger slot windows of the two-wave budget do (19 vs 35 ms at N = 64, 960x540) — provided
+// three workgroups of the small budget really fit the CU's 160 KiB (a scene with many spheres can push the third workgroup out, and the small budget at two
+// waves per SIMD is the worst of both).  SKR_OCC=2|3 forces one (A/B runs).
+static int wave_occ_for(const RenderParams &p)
+{
+	const char *e = getenv("SKR_OCC");
+	if(e) return atoi(e) >= 3 ? 3 : 2;
+	// (and for gillum < 8 the small budget's 8-parent groups cannot fill a 64-lane round)
+	if(p.monte_carlo && p.n_spheres > 0 && p.max_depth > 1 && (p.num_path_traces > 32 || p.num_path_traces < 8)) return 2;
+	// measured on MI355X: LDS is granted in 1280-byte granules (160 KiB / 128): 3 x 53,264 B and
+	// 2 x 81,680 B are resident together, 3 x 53,904 B and 2 x 81,936 B are not
+	const size_t granule = 1280, cu_lds = 160 * 1024;
+	const size_t blk3 = (wave_block_lds(p, 3) + granule - 1) / granule * granule;
+	return 3 * blk3 <= cu_lds ? 3 : 2;
+}
+
+size_t skr_wave_lds_bytes(const RenderParams &p) { return wave_block_lds(p, wave_occ_for(p)); }
 
 // The streaming kernel covers --depth 1..3, gillum <= 256, <= 65535 spheres.
 bool skr_wave_supported(const RenderParams &p)

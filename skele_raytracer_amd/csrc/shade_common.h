@@ -207,7 +207,8 @@ SKR_DEV f3 direct_light(const SceneView &sv, const RenderParams &p, int sph, f3 
 
 // raytrace.h:22-30 + :117-125: hemisphere sample and the reference's basis mix
 // (perp_to_both.y/.z where perp_to_normal.y/.z belongs — kept).
-SKR_DEV f3 gi_direction(float r1, float r2, f3 N, f3 nt, f3 nb)
+// (out of line together with the binary64 sincos it calls: see device_math.h)
+static __device__ __attribute__((noinline)) f3 gi_direction(float r1, float r2, f3 N, f3 nt, f3 nb)
 {
 	const float s_theta = sk_sqrtf(1 - r1 * r1);
 	const float phi = (float) ((2.0 * 3.14159265358979323846) * (double) r2); // (2.0f*M_PI)*r2 in double, narrowed
