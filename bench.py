@@ -141,6 +141,16 @@ def main():
         scene_bytes = info.n_spheres * 64 + info.n_point_lights * 32 + info.n_triangles * 48
         launch_bytes = W * min(H, k_max * TILE_ROWS) * 3 + scene_bytes
         achieved_gbs = launch_bytes / (kernel_ms * 1e-3) / 1e9
+        # HBM bytes per launch from PMC counters cannot be collected from inside this process; the figure of the
+        # last committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command is reported (N=1 only)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+                tj = json.load(f)
+            if world == 1 and tj.get("kernel", "").startswith("skr_wave_kernel") and r.kernel_variant().startswith("wave"):
+                traffic = tj["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         # algorithmic flops: 34 flop per ray-sphere test; per radiance ray n_sph tests,
         # per shadow ray at most n_sph (early-out ignored => upper bound), ~150 flop shading per hit
         alg_flop = (rays_per_frame * info.n_spheres + shadow / args.steps * info.n_spheres) * 34 + hits / args.steps * 150
@@ -156,7 +166,8 @@ def main():
                        "gather": "RCCL all-gather of the u8 tile buffers, rank 0 de-interleaves" if world > 1 else "none (1 GPU)",
                        "kernel": r.kernel_variant(), "seed": KW["seed"]},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; FETCH doubled per the gfx950 note)" if traffic else None,
                          "kernel": "skr_wave_kernel<3>" if r.kernel_variant().startswith("wave") else "skr_render_kernel<3>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": launch_bytes,
                          "note": "compulsory HBM traffic is the u8 framebuffer + ~1 KB of scene: this path is FP32-VALU bound, see roofline_valu"},
             "roofline_valu": {"bound": "fp32_valu", "achieved": alg_flop / (kernel_ms * 1e-3) / 1e12 / world * 1.0,
