@@ -195,3 +195,44 @@ def test_cli_drop_in_writes_the_same_ppm(gpu, oracle, tmp_path):
     assert res.returncode == 0 and "depth takes a positive int" in res.stderr
     res = subprocess.run([exe, "--path", str(tmp_path / "nope.scn"), "--output", out], capture_output=True, text=True, timeout=60)
     assert res.returncode == 0 and "Can't open file" in res.stdout
+
+
+def _write_synthetic_scn(path, rng, n_spheres, n_lights, n_tris):
+    """A random but well-conditioned scene in the reference's .scn grammar."""
+    lines = ["camera 0 1.5 -9 0 -.05 1 0 1 0 30", "background .1 .2 .3", "ambient_light .3 .3 .3"]
+    lines += ["material .6 .6 .6 .7 .7 .7 .2 .2 .2 8 0 0 0 1", "sphere 0 -40 0 40"]
+    for _ in range(n_spheres - 1):
+        ka, kd, ks = rng.random(3), rng.random(3), rng.random(3) * 0.5
+        lines.append("material %g %g %g %g %g %g %g %g %g %d 0 0 0 1" % (*ka, *kd, *ks, int(rng.choice([1, 2, 7, 16, 33, 100]))))
+        lines.append("sphere %g %g %g %g" % (rng.uniform(-6, 6), rng.uniform(0.2, 4), rng.uniform(-3, 8), rng.uniform(0.3, 1.2)))
+    lines.append("material 0 0 0 .5 .5 .5 .5 .5 .5 2.5 0 0 0 1")  # non-integer phong power: general pow branch
+    lines.append("sphere 2 1 -2 .8")
+    for _ in range(3 * n_tris):
+        lines.append("vertex %g %g %g" % (rng.uniform(-5, 5), rng.uniform(0, 5), rng.uniform(2, 9)))
+    for i in range(n_tris):
+        lines.append("triangle %d %d %d" % (3 * i, 3 * i + 1, 3 * i + 2))
+    for _ in range(n_lights):
+        lines.append("point_light %g %g %g %g %g %g" % (*rng.uniform(5, 40, 3), rng.uniform(-8, 8), rng.uniform(3, 9), rng.uniform(-8, 8)))
+    open(path, "w").write("\n".join(lines) + "\n")
+
+
+@pytest.mark.parametrize("n_spheres,n_lights,n_tris,kw", [
+    (40, 3, 0, dict(gillum=6, shadow=True, seed=1)),     # odd light count, > 32 spheres (large LDS budget)
+    (9, 1, 5, dict(gillum=8, shadow=True, seed=2)),      # one light, a few triangles among GI rays
+    (5, 0, 0, dict(gillum=4, shadow=True, seed=3)),      # no lights at all
+    (70, 5, 3, dict(jsample=2, shadow=True, seed=4)),    # many lights, no GI
+    (3, 2, 0, dict(gillum=9, depth=2, seed=5)),
+], ids=["40s3l", "9s1l5t", "5s0l", "70s5l3t", "3s2l_d2"])
+def test_synthetic_scenes_match_oracle(gpu, oracle, tmp_path, n_spheres, n_lights, n_tris, kw):
+    rng = np.random.default_rng(n_spheres * 1000 + n_lights)
+    scn = str(tmp_path / "synthetic.scn")
+    _write_synthetic_scn(scn, rng, n_spheres, n_lights, n_tris)
+    w, h = 96, 54
+    sc = skr.parse_scene(scn)
+    r = skr.Renderer(sc)
+    rgb, rgbf = r.render(skr.Options(w, h, **kw), want_float=True)
+    gpu.cuda.synchronize()
+    o_rgb, o_f, st = oracle.render(scn, w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, **kw)
+    compare(rgb.cpu().numpy(), rgbf.cpu().numpy(), o_rgb, o_f, "synthetic %d/%d/%d" % (n_spheres, n_lights, n_tris))
+    cnt = r.counters()
+    assert cnt["radiance_rays"] == int(st[0]) and cnt["sphere_hits"] == int(st[1])
