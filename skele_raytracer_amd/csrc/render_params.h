@@ -14,6 +14,7 @@ struct RenderParams {
 	// image and partition (include/skr.h skr_render_tiles)
 	int32_t width, height;
 	uint32_t tile_rows, first_tile, tile_stride, out_rows;
+	int32_t tile_w_log2, tile_h_log2; // per-wave pixel tile of the streaming kernel: 8x8, 8x4 or 4x4 (set by its launcher)
 	// per-frame invariants of main.cpp:134-137, computed once on the host
 	float inv_width, inv_height, aspect, angle;
 	// camera.h:8-32 (direction/up/right keep the file's magnitudes) and scene.h:24

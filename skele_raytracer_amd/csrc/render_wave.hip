@@ -720,14 +720,19 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 	float *gres = wbase + C::REGION0_FLOATS + 64;
 	unsigned char *s_tile = reinterpret_cast<unsigned char *>(gres + C::PAR0_MAX * 3);
 
-	const int lx = lane & 7, ly = lane >> 3;
-	const int x0 = (blockIdx.x * 2 + (wave & 1)) * 8;
-	const uint32_t orow0 = (blockIdx.y * 2 + (wave >> 1)) * 8;
+	// A wave's tile is 8x8, 8x4 or 4x4 pixels (p.tile_w_log2/p.tile_h_log2): small launches (one
+	// GPU's share of a frame sharded 8 ways) use smaller tiles so that there are several tiles per
+	// wave slot and one deep tile cannot dominate the frame time.  Lanes beyond the tile idle in the
+	// primary pass only; the --gillum rounds are packed by (parent, child) regardless.
+	const int tw = 1 << p.tile_w_log2, th = 1 << p.tile_h_log2;
+	const int lx = lane & (tw - 1), ly = lane >> p.tile_w_log2;
+	const int x0 = (blockIdx.x * 2 + (wave & 1)) * tw;
+	const uint32_t orow0 = (blockIdx.y * 2 + (wave >> 1)) * (uint32_t) th;
 	const int x = x0 + lx;
 	const uint32_t orow = orow0 + ly;
 	const uint32_t k = orow / p.tile_rows;
 	const uint32_t y = (p.first_tile + k * p.tile_stride) * p.tile_rows + (orow - k * p.tile_rows);
-	const bool valid = x < p.width && orow < p.out_rows && y < (uint32_t) p.height;
+	const bool valid = ly < th && x < p.width && orow < p.out_rows && y < (uint32_t) p.height;
 	const uint32_t pixel = y * (uint32_t) p.width + (uint32_t) x;
 
 	Counters cn{0, 0, 0};
@@ -768,24 +773,28 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 	}
 	if(p.rgb)
 	{ // pack to u8 in LDS, then store the tile's 8 rows x 24 bytes as 48 dwords
-		unsigned char *t = s_tile + (ly * 8 + lx) * 3;
-		t[0] = (unsigned char) quantise(px.x);
-		t[1] = (unsigned char) quantise(px.y);
-		t[2] = (unsigned char) quantise(px.z);
-		wave_lds_fence();
-		const bool full = (x0 + 8 <= p.width) && ((p.width & 3) == 0);
-		if(full)
+		unsigned char *t = s_tile + ((ly & 7) * tw + lx) * 3;
+		if(ly < th)
 		{
-			if(lane < 48)
+			t[0] = (unsigned char) quantise(px.x);
+			t[1] = (unsigned char) quantise(px.y);
+			t[2] = (unsigned char) quantise(px.z);
+		}
+		wave_lds_fence();
+		const bool full = (x0 + tw <= p.width) && ((p.width & 3) == 0);
+		if(full)
+		{ // th rows of tw*3 bytes (24 or 12) = dw dwords each
+			const int dw = (tw * 3) >> 2;
+			if(lane < th * dw)
 			{
-				const int row = lane / 6, j = lane - row * 6;
+				const int row = lane / dw, j = lane - row * dw;
 				const uint32_t orow2 = orow0 + row;
 				const uint32_t k2 = orow2 / p.tile_rows;
 				const uint32_t y2 = (p.first_tile + k2 * p.tile_stride) * p.tile_rows + (orow2 - k2 * p.tile_rows);
 				if(orow2 < p.out_rows && y2 < (uint32_t) p.height)
 				{
 					uint32_t *dst = reinterpret_cast<uint32_t *>(p.rgb + ((size_t) orow2 * p.width + x0) * 3);
-					dst[j] = reinterpret_cast<const uint32_t *>(s_tile + row * 24)[j];
+					dst[j] = reinterpret_cast<const uint32_t *>(s_tile + row * tw * 3)[j];
 				}
 			}
 		}
@@ -859,9 +868,31 @@ static hipError_t launch_wave_depth(const RenderParams &p, dim3 grid, size_t lds
 	return hipGetLastError();
 }
 
-hipError_t skr_launch_wave(const RenderParams &p, hipStream_t stream)
+hipError_t skr_launch_wave(const RenderParams &p_in, hipStream_t stream)
 {
-	const dim3 grid((p.width + 15) / 16, (p.out_rows + 15) / 16);
+	RenderParams p = p_in;
+	// tile shape.  Measured on the headline frame (tools/time_shard.py, slowest rank's kernel, ms):
+	//   share of the frame   8x8     8x4     4x4
+	//   1/1                  3.12    3.03    3.30
+	//   1/2                  2.11    1.55    1.64
+	//   1/4                  1.78    1.04    0.84
+	//   1/8                  1.76    0.98    0.55
+	// one deep 8x8 tile alone takes ~1.7 ms, so 8x8 stops scaling at two GPUs.  Default 8x4; 4x4 once
+	// a launch has fewer than ~8 8x4-tiles per resident wave slot.  Without --gillum trees there is
+	// nothing to balance and 8x8 keeps every primary-pass lane busy.  SKR_TILE=64|32|16 forces a shape.
+	int tile_px = 32;
+	{
+		const uint64_t slots = 256ull * 4 * 3;
+		const uint64_t pixels = (uint64_t) p.width * p.out_rows;
+		if(pixels / 32 < 8 * slots) tile_px = 16;
+		if(!p.monte_carlo || p.n_spheres == 0 || p.max_depth < 2) tile_px = 64;
+		const char *e = getenv("SKR_TILE");
+		if(e && (atoi(e) == 64 || atoi(e) == 32 || atoi(e) == 16)) tile_px = atoi(e);
+	}
+	p.tile_w_log2 = tile_px == 16 ? 2 : 3;
+	p.tile_h_log2 = tile_px == 64 ? 3 : 2;
+	const int tw = 1 << p.tile_w_log2, th = 1 << p.tile_h_log2;
+	const dim3 grid((p.width + 2 * tw - 1) / (2 * tw), (p.out_rows + 2 * th - 1) / (2 * th));
 	const size_t lds = skr_wave_lds_bytes(p);
 	const bool occ3 = wave_occ_for(p) == 3;
 	// without --gillum shade() never recurses (raytrace.h:208-218), and without spheres nothing is ever
