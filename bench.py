@@ -111,6 +111,8 @@ def main():
         step()
     sync()
     r.counters(reset=True)
+    r.kernel_timing(True)
+    r.kernel_ms()  # drop the warm-up launches
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     sync()
     t0 = time.perf_counter()
@@ -119,16 +121,18 @@ def main():
     sync()
     dt = time.perf_counter() - t0
 
+    queued = r.last_parent_count() if r.kernel_variant().startswith("parent_queue") else 0  # before the counters are reset
     cnt = r.counters(reset=True)
-    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
-    stats = torch.tensor([dt, float(cnt["radiance_rays"]), float(cnt["shadow_rays"]), float(cnt["sphere_hits"]), kernel_ms],
+    pipeline_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)  # everything this rank enqueues per frame before the collective
+    kernel_ms, timed_launches = r.kernel_ms()                                      # the dominant kernel alone (HIP events on its stream)
+    stats = torch.tensor([dt, float(cnt["radiance_rays"]), float(cnt["shadow_rays"]), float(cnt["sphere_hits"]), kernel_ms, pipeline_ms],
                          dtype=torch.float64, device=dev)
     if world > 1:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        dt, kernel_ms = float(mx[0]), float(mx[4])
+        dt, kernel_ms, pipeline_ms = float(mx[0]), float(mx[4]), float(mx[5])
         rays, shadow, hits = float(sm[1]), float(sm[2]), float(sm[3])
     else:
         rays, shadow, hits = float(stats[1]), float(stats[2]), float(stats[3])
@@ -136,10 +140,13 @@ def main():
     if rank == 0:
         rays_per_frame = rays / args.steps
         info = scene.info
-        # algorithmic HBM bytes of one launch of the dominant kernel on this rank: its share of the
-        # u8 framebuffer + one read of the scene ((W*H*3 + scene bytes) per frame)
+        # algorithmic HBM bytes of one launch of the dominant kernel on this rank:
+        #  single megakernel: its share of the u8 framebuffer + one read of the scene
+        #  parent-queue pipeline: the GI kernel reads one 64-byte record per primary hit and writes that pixel (3 B)
         scene_bytes = info.n_spheres * 64 + info.n_point_lights * 32 + info.n_triangles * 48
-        launch_bytes = W * min(H, k_max * TILE_ROWS) * 3 + scene_bytes
+        frame_bytes = W * min(H, k_max * TILE_ROWS) * 3
+        n_parents = queued
+        launch_bytes = (n_parents * (64 + 3) + scene_bytes) if n_parents else (frame_bytes + scene_bytes)
         achieved_gbs = launch_bytes / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per launch from PMC counters cannot be collected from inside this process; the figure of the
         # last committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command is reported (N=1 only)
@@ -147,7 +154,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
                 tj = json.load(f)
-            if world == 1 and tj.get("kernel", "").startswith("skr_wave_kernel") and r.kernel_variant().startswith("wave"):
+            if world == 1 and tj.get("variant") == r.kernel_variant():
                 traffic = tj["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
@@ -168,8 +175,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; FETCH doubled per the gfx950 note)" if traffic else None,
-                         "kernel": "skr_wave_kernel<3>" if r.kernel_variant().startswith("wave") else "skr_render_kernel<3>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": launch_bytes,
-                         "note": "compulsory HBM traffic is the u8 framebuffer + ~1 KB of scene: this path is FP32-VALU bound, see roofline_valu"},
+                         "kernel": {"parent_queue_v3": "skr_gi_kernel<3, 3>", "wave_streaming_v2": "skr_wave_kernel<3, 3>"}.get(r.kernel_variant(), "skr_render_kernel<3>"), "kernel_ms": kernel_ms, "render_ms": pipeline_ms, "algorithmic_bytes_per_launch": launch_bytes, "frame_bytes": frame_bytes, "queued_parents": n_parents,
+                         "note": "HBM traffic is the parent queue (64 B per primary hit) + the u8 framebuffer + ~1 KB of scene: this path is FP32-VALU bound, see roofline_valu"},
             "roofline_valu": {"bound": "fp32_valu", "achieved": alg_flop / (kernel_ms * 1e-3) / 1e12 / world * 1.0,
                               "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": alg_flop / (kernel_ms * 1e-3) / 1e12 / world / VALU_PEAK_TFLOPS,
                               "note": "algorithmic flops (34/sphere test, 150/shaded hit; shadow early-outs ignored) per GPU / peak FP32 vector"},

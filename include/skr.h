@@ -121,6 +121,14 @@ int skr_render_rows(skr_renderer *r, const skr_options *opt, uint32_t y0, uint32
  * out[0] radiance rays = shade() calls with depth > 0, out[1] sphere hits shaded,
  * out[2] shadow rays (one per light per hit; the reference casts each twice). */
 int skr_renderer_read_counters(skr_renderer *r, uint64_t out[3], int reset);
+/* Time the dominant kernel of each launch with HIP events recorded on the launch stream (off by
+ * default).  skr_renderer_kernel_ms() waits for the launches made since the last call and returns
+ * their mean duration in ms and their number: what bench.py's roofline is computed from. */
+int skr_renderer_kernel_timing(skr_renderer *r, int enable);
+int skr_renderer_kernel_ms(skr_renderer *r, float *mean_ms, int32_t *launches);
+/* Number of primary sphere hits the last launch queued for the --gillum kernel (0 if that launch did not
+ * use the parent queue); synchronous.  bench.py sizes the GI kernel's algorithmic HBM bytes with it. */
+int skr_renderer_last_parent_count(skr_renderer *r, uint32_t *n);
 /* Whole frame into HOST memory (W*H*3 bytes), synchronous; what the CLI uses. */
 int skr_render_frame_host(skr_renderer *r, const skr_options *opt, uint8_t *h_rgb, float *kernel_ms);
 

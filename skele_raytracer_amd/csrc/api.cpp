@@ -12,9 +12,11 @@
 #include "render_params.h"
 #include "scene_host.h"
 
-hipError_t skr_launch_render(const RenderParams &p, hipStream_t stream, const char **variant);
+hipError_t skr_launch_render(const RenderParams &p, hipStream_t stream, const char **variant, const SkrTimingHook *hook);
 hipError_t skr_launch_debug(int op, const void *d_in, void *d_out, uint32_t n, hipStream_t stream);
 size_t skr_render_lds_bytes(const RenderParams &p);
+bool skr_queue_selected(const RenderParams &p);
+void skr_queue_scratch_bytes(const RenderParams &p, size_t *parent_bytes, size_t *acc_bytes);
 
 static thread_local const char *g_variant = "none";
 
@@ -36,6 +38,15 @@ struct skr_renderer {
 	size_t off_amb = 0, off_kd = 0, off_ks = 0, off_lights = 0, off_tris = 0;
 	unsigned long long *d_counters = nullptr;
 	int lds_limit = 0;
+	// scratch of the parent-queue pipeline, grown on demand and kept
+	void *d_parents = nullptr;
+	size_t parents_cap = 0;
+	float *d_acc = nullptr;
+	size_t acc_cap = 0;
+	// skr_renderer_kernel_ms: event pairs around the dominant kernel of recent launches
+	bool timing = false;
+	std::vector<SkrTimingHook> timed;
+	std::vector<SkrTimingHook> free_pairs;
 };
 
 extern "C" {
@@ -92,8 +103,8 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	if(nt3) memcpy(&blob[r->off_tris], scene->tris.data(), nt3 * 16);
 	hipError_t e = hipMalloc((void **) &r->d_blob, blob.size() * 16);
 	if(e == hipSuccess) e = hipMemcpy(r->d_blob, blob.data(), blob.size() * 16, hipMemcpyHostToDevice);
-	if(e == hipSuccess) e = hipMalloc((void **) &r->d_counters, (SKR_COUNTER_SHARDS * 4 + 8) * sizeof(unsigned long long));
-	if(e == hipSuccess) e = hipMemset(r->d_counters, 0, (SKR_COUNTER_SHARDS * 4 + 8) * sizeof(unsigned long long));
+	if(e == hipSuccess) e = hipMalloc((void **) &r->d_counters, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long));
+	if(e == hipSuccess) e = hipMemset(r->d_counters, 0, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long));
 	if(e != hipSuccess)
 	{
 		skr_set_error("scene upload failed: %s", hipGetErrorString(e));
@@ -112,6 +123,10 @@ void skr_renderer_destroy(skr_renderer *r)
 	(void) hipSetDevice(r->device);
 	if(r->d_blob) (void) hipFree(r->d_blob);
 	if(r->d_counters) (void) hipFree(r->d_counters);
+	if(r->d_parents) (void) hipFree(r->d_parents);
+	if(r->d_acc) (void) hipFree(r->d_acc);
+	for(SkrTimingHook &h : r->timed) { (void) hipEventDestroy(h.start); (void) hipEventDestroy(h.stop); }
+	for(SkrTimingHook &h : r->free_pairs) { (void) hipEventDestroy(h.start); (void) hipEventDestroy(h.stop); }
 	delete r;
 }
 
@@ -210,13 +225,52 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.rgb = d_rgb;
 	p.rgbf = d_rgbf;
 	p.counters = r->d_counters;
+	p.qctr = reinterpret_cast<uint32_t *>(r->d_counters + (size_t) SKR_COUNTER_SHARDS * 4 + 8);
+	if(skr_queue_selected(p))
+	{ // grow the pipeline's scratch if this launch needs more (first call / larger frame only)
+		size_t need_par = 0, need_acc = 0;
+		skr_queue_scratch_bytes(p, &need_par, &need_acc);
+		if(need_par > r->parents_cap)
+		{
+			if(r->d_parents) SKR_HIP(hipFree(r->d_parents));
+			r->d_parents = nullptr;
+			r->parents_cap = 0;
+			SKR_HIP(hipMalloc(&r->d_parents, need_par));
+			r->parents_cap = need_par;
+		}
+		if(need_acc > r->acc_cap)
+		{
+			if(r->d_acc) SKR_HIP(hipFree(r->d_acc));
+			r->d_acc = nullptr;
+			r->acc_cap = 0;
+			SKR_HIP(hipMalloc((void **) &r->d_acc, need_acc));
+			r->acc_cap = need_acc;
+		}
+		p.parents = reinterpret_cast<float4 *>(r->d_parents);
+		p.acc = r->d_acc;
+	}
 	if(skr_render_lds_bytes(p) > (size_t) r->lds_limit)
 	{
 		skr_set_error("scene needs %zu bytes of LDS (%d spheres, %d lights); the device allows %d per workgroup", skr_render_lds_bytes(p),
 					  p.n_spheres, p.n_lights, r->lds_limit);
 		return SKR_ERR_UNSUPPORTED;
 	}
-	SKR_HIP(skr_launch_render(p, (hipStream_t) stream, &g_variant));
+	SkrTimingHook hook;
+	if(r->timing)
+	{
+		if(!r->free_pairs.empty())
+		{
+			hook = r->free_pairs.back();
+			r->free_pairs.pop_back();
+		}
+		else
+		{
+			SKR_HIP(hipEventCreate(&hook.start));
+			SKR_HIP(hipEventCreate(&hook.stop));
+		}
+	}
+	SKR_HIP(skr_launch_render(p, (hipStream_t) stream, &g_variant, r->timing ? &hook : nullptr));
+	if(r->timing) r->timed.push_back(hook);
 	return SKR_OK;
 }
 
@@ -244,11 +298,47 @@ int skr_render_rows(skr_renderer *r, const skr_options *opt, uint32_t y0, uint32
 	return render_impl(r, opt, a, y0 / a, 1, (y1 - y0) / a, d_rgb, d_rgbf, stream);
 }
 
+int skr_renderer_kernel_timing(skr_renderer *r, int enable)
+{
+	if(!r) return SKR_ERR_ARG;
+	r->timing = enable != 0;
+	return SKR_OK;
+}
+
+int skr_renderer_kernel_ms(skr_renderer *r, float *mean_ms, int32_t *launches)
+{
+	if(!r || !mean_ms) return SKR_ERR_ARG;
+	SKR_HIP(hipSetDevice(r->device));
+	double sum = 0;
+	int n = 0;
+	for(SkrTimingHook &h : r->timed)
+	{
+		SKR_HIP(hipEventSynchronize(h.stop));
+		float ms = 0;
+		SKR_HIP(hipEventElapsedTime(&ms, h.start, h.stop));
+		sum += ms;
+		n++;
+		r->free_pairs.push_back(h);
+	}
+	r->timed.clear();
+	*mean_ms = n ? (float) (sum / n) : 0.0f;
+	if(launches) *launches = n;
+	return SKR_OK;
+}
+
+int skr_renderer_last_parent_count(skr_renderer *r, uint32_t *n)
+{
+	if(!r || !n) return SKR_ERR_ARG;
+	SKR_HIP(hipSetDevice(r->device));
+	SKR_HIP(hipMemcpy(n, r->d_counters + (size_t) SKR_COUNTER_SHARDS * 4 + 8, sizeof(uint32_t), hipMemcpyDeviceToHost));
+	return SKR_OK;
+}
+
 int skr_renderer_read_counters(skr_renderer *r, uint64_t out[3], int reset)
 {
 	if(!r || !out) return SKR_ERR_ARG;
 	SKR_HIP(hipSetDevice(r->device));
-	std::vector<unsigned long long> h((size_t) SKR_COUNTER_SHARDS * 4 + 8);
+	std::vector<unsigned long long> h((size_t) SKR_COUNTER_SHARDS * 4 + 16);
 	SKR_HIP(hipMemcpy(h.data(), r->d_counters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost)); // synchronises with prior launches
 	out[0] = out[1] = out[2] = 0;
 	for(size_t s = 0; s < SKR_COUNTER_SHARDS; s++)

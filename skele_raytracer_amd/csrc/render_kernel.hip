@@ -184,6 +184,8 @@ __global__ __launch_bounds__(256) void skr_render_kernel(const RenderParams p)
 size_t skr_wave_lds_bytes(const RenderParams &p);
 bool skr_wave_supported(const RenderParams &p);
 hipError_t skr_launch_wave(const RenderParams &p, hipStream_t stream);
+bool skr_queue_selected(const RenderParams &p);
+hipError_t skr_launch_queue(const RenderParams &p, hipStream_t stream, const SkrTimingHook *hook);
 
 // The wave-streaming kernel is the product path wherever it applies (depth <= 3, gillum <= 256);
 // the per-pixel kernel covers the rest (depth 4..6).  SKR_KERNEL=v1 forces the latter (A/B runs).
@@ -207,26 +209,38 @@ static hipError_t launch_depth(const RenderParams &p, dim3 grid, size_t lds, hip
 	return hipGetLastError();
 }
 
-hipError_t skr_launch_render(const RenderParams &p, hipStream_t stream, const char **variant)
+hipError_t skr_launch_render(const RenderParams &p, hipStream_t stream, const char **variant, const SkrTimingHook *hook)
 {
 	if(use_wave_kernel(p))
 	{
+		if(skr_queue_selected(p) && p.parents && p.qctr)
+		{
+			*variant = "parent_queue_v3";
+			return skr_launch_queue(p, stream, hook);
+		}
 		*variant = "wave_streaming_v2";
-		return skr_launch_wave(p, stream);
+		if(hook && hook->start) (void) hipEventRecord(hook->start, stream);
+		const hipError_t e = skr_launch_wave(p, stream);
+		if(hook && hook->stop) (void) hipEventRecord(hook->stop, stream);
+		return e;
 	}
 	const dim3 grid((p.width + 15) / 16, (p.out_rows + 15) / 16);
 	const size_t lds = skr_render_lds_bytes(p);
 	*variant = "lane_per_pixel_dfs_v1f";
+	if(hook && hook->start) (void) hipEventRecord(hook->start, stream);
+	hipError_t e = hipErrorInvalidValue;
 	switch(p.max_depth)
 	{
-		case 1: return launch_depth<1>(p, grid, lds, stream);
-		case 2: return launch_depth<2>(p, grid, lds, stream);
-		case 3: return launch_depth<3>(p, grid, lds, stream);
-		case 4: return launch_depth<4>(p, grid, lds, stream);
-		case 5: return launch_depth<5>(p, grid, lds, stream);
-		case 6: return launch_depth<6>(p, grid, lds, stream);
-		default: return hipErrorInvalidValue;
+		case 1: e = launch_depth<1>(p, grid, lds, stream); break;
+		case 2: e = launch_depth<2>(p, grid, lds, stream); break;
+		case 3: e = launch_depth<3>(p, grid, lds, stream); break;
+		case 4: e = launch_depth<4>(p, grid, lds, stream); break;
+		case 5: e = launch_depth<5>(p, grid, lds, stream); break;
+		case 6: e = launch_depth<6>(p, grid, lds, stream); break;
+		default: break;
 	}
+	if(hook && hook->stop) (void) hipEventRecord(hook->stop, stream);
+	return e;
 }
 
 // ------------------------------------------------------------ debug eval ----

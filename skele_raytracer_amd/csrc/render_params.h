@@ -29,4 +29,15 @@ struct RenderParams {
 	uint8_t *rgb;
 	float *rgbf;
 	unsigned long long *counters; // SKR_COUNTER_SHARDS x {radiance rays, sphere hits shaded, shadow rays, pad}
+	// parent-queue pipeline (render_wave.hip: skr_primary_kernel -> skr_gi_kernel -> skr_resolve_kernel)
+	float4 *parents;    // 4 x float4 per primary hit: co.xyz N.x | N.yz direct.xy | direct.z kd.xyz | pixel, out_pix, -, -
+	uint32_t *qctr;     // [0] number of parents appended, [1] next group to hand out
+	float *acc;         // float3 per output pixel: the running `image[y][x] += shade(...)` of main.cpp:162 (AA only)
+	uint32_t aa_index;  // which AA sample this launch traces
+};
+
+// Optional timing of the dominant kernel of a launch (skr_renderer_kernel_ms): the launcher records the
+// two events right around that kernel on the launch stream.
+struct SkrTimingHook {
+	hipEvent_t start = nullptr, stop = nullptr;
 };

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "shade_common.h"
 
@@ -568,6 +569,31 @@ SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, int m, Cou
 	}
 }
 
+// All child rays (and, at depth 3, grandchild rays) of the gp parents in the wave's LDS parent table:
+// afterwards slot region 0 holds every parent's N accumulation terms (raytrace.h:130).
+template <int DEPTH>
+SKR_DEV void run_group(const Wave &w, int gp, Queue &q1, Queue &q2, Counters &cn STAMP_ARG)
+{
+	const ParSrc src0{nullptr, w.par0_tbl};
+	const int ntasks = gp * w.N;
+	for(int task0 = 0; task0 < ntasks; task0 += 64)
+	{
+		const bool last = task0 + 64 >= ntasks;
+		if constexpr(DEPTH == 2)
+		{
+			child_round(w, src0, 0, gp, task0, 0, q2, cn);
+			while(q2.count >= 64 || (last && q2.count > 0)) shade_leaf_batch(w, q2, src0, q2.count < 64 ? q2.count : 64, cn);
+		}
+		else
+		{
+			child_round(w, src0, 0, gp, task0, 0, q1, cn);
+			STAMP(1);
+			while(q1.count >= w.act_max || (last && q1.count > 0)) expand_level1_batch(w, q1, q2, q1.count < w.act_max ? q1.count : w.act_max, cn STAMP_PASS);
+		}
+	}
+	wave_lds_fence();
+}
+
 // One sample of every pixel of the wave's tile: raytrace.h:139-227 at depth DEPTH.
 template <int DEPTH>
 SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pixel, Queue &q1, Queue &q2, int *lane_tbl, float *gres, Counters &cn STAMP_ARG)
@@ -610,7 +636,6 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 		const int n0 = (int) __popcll(M0);
 		const int rank = lanes_below(M0);
 		const int G = uni(w.s0_max / (w.N > 0 ? w.N : 1) < w.par0_max ? w.s0_max / (w.N > 0 ? w.N : 1) : w.par0_max);
-		const ParSrc src0{nullptr, w.par0_tbl};
 		for(int g0 = 0; g0 < n0 && w.N > 0; g0 += G)
 		{
 			const int gp = uni(n0 - g0 < G ? n0 - g0 : G);
@@ -631,23 +656,7 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 				}
 				wave_lds_fence();
 			}
-			const int ntasks = gp * w.N;
-			for(int task0 = 0; task0 < ntasks; task0 += 64)
-			{
-				const bool last = task0 + 64 >= ntasks;
-				if constexpr(DEPTH == 2)
-				{
-					child_round(w, src0, 0, gp, task0, 0, q2, cn);
-					while(q2.count >= 64 || (last && q2.count > 0)) shade_leaf_batch(w, q2, src0, q2.count < 64 ? q2.count : 64, cn);
-				}
-				else
-				{
-					child_round(w, src0, 0, gp, task0, 0, q1, cn);
-					STAMP(1);
-					while(q1.count >= w.act_max || (last && q1.count > 0)) expand_level1_batch(w, q1, q2, q1.count < w.act_max ? q1.count : w.act_max, cn STAMP_PASS);
-				}
-			}
-			wave_lds_fence();
+			run_group<DEPTH>(w, gp, q1, q2, cn STAMP_PASS);
 			if(w.lane < gp)
 			{
 				const f3 total = sum_slots(w, 0, w.lane);
@@ -827,6 +836,294 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 
 // gillum <= 32: the 3-waves-per-SIMD budget wins (3.6 vs 4.1 ms at N = 16); above, the larger slot
 // windows of the 2-wave budget do (21.9 vs 35 ms at N = 64, 960x540).  Measured: DESIGN.md §6.
+// =====================================================================================
+// Parent-queue pipeline (the product path for --gillum at depth 2..3).
+//
+// Inside one megakernel launch a wave's latency is set by its deepest pixel tile (one 8x8 tile of
+// ground pixels takes ~1.7 ms of the 3.1 ms frame), which caps strong scaling and leaves waves with
+// sparse tiles half empty.  Here the tree is cut once, under the primary hit:
+//   skr_primary_kernel   primary rays + direct light for every pixel; each sphere hit appends a
+//                        64-byte parent record (ballot + one atomic per workgroup) to a device queue
+//   skr_gi_kernel        persistent waves pull groups of G parents from the queue and run the same
+//                        level-synchronous streaming as skr_wave_kernel (run_group), then finish
+//                        `(direct/pi + 2*indirect) * kd` (raytrace.h:213) and write the pixel
+//   skr_resolve_kernel   (AA only) `image /= g*g` (main.cpp:165) and the u8 quantiser
+// Work items are 8..16 parents (a few hundred rays) instead of 32..64 pixels with their whole trees.
+// Values are the same spec: the image is bit-identical to the single-kernel path.
+// =====================================================================================
+
+namespace {
+
+SKR_DEV void primary_ray(const RenderParams &p, int x, uint32_t y, uint32_t pixel, uint32_t aa, f3 &dir)
+{ // main.cpp:140-182
+	float u, v;
+	if(p.grid_size > 0)
+	{
+		uint32_t rnd[4];
+		philox4x32_10(pixel, aa, 0u, 0xFFFFFFFFu, p.seed_lo, p.seed_hi, rnd);
+		const float r = u31_to_unit(rnd[0]);
+		u = ((2 * (((float) x + r) * p.inv_width) - 1) * p.angle) * p.aspect;
+		v = (1 - 2 * (((float) (int) y + r) * p.inv_height)) * p.angle;
+	}
+	else
+	{
+		u = (float) (((2 * (((double) x + 0.5) * (double) p.inv_width) - 1) * (double) p.angle) * (double) p.aspect);
+		v = (float) ((1 - 2 * (((double) (int) y + 0.5) * (double) p.inv_height)) * (double) p.angle);
+	}
+	dir = (p.cam_dir + p.cam_right * u) + p.cam_up * v;
+}
+
+SKR_DEV void emit_sample(const RenderParams &p, uint32_t out_pix, f3 c)
+{ // one sample of one pixel is final: store it (1 spp) or add it to the running sum (AA, sample order = launch order)
+	if(p.grid_size > 0)
+	{
+		float *a = p.acc + (size_t) out_pix * 3;
+		if(p.aa_index == 0) { a[0] = c.x; a[1] = c.y; a[2] = c.z; }
+		else { a[0] = a[0] + c.x; a[1] = a[1] + c.y; a[2] = a[2] + c.z; }
+	}
+	else
+	{
+		if(p.rgbf)
+		{
+			float *o = p.rgbf + (size_t) out_pix * 3;
+			o[0] = c.x; o[1] = c.y; o[2] = c.z;
+		}
+		if(p.rgb)
+		{
+			unsigned char *o = p.rgb + (size_t) out_pix * 3;
+			o[0] = (unsigned char) quantise(c.x);
+			o[1] = (unsigned char) quantise(c.y);
+			o[2] = (unsigned char) quantise(c.z);
+		}
+	}
+}
+
+} // namespace
+
+// One workgroup = a 16x16 pixel block, one lane per pixel.
+__global__ __launch_bounds__(256) void skr_primary_kernel(const RenderParams p)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
+	const int ns = p.n_spheres, nl = p.n_lights;
+	float4 *s_geom = lds4, *s_amb = lds4 + ns + 1, *s_kd = s_amb + ns, *s_ks = s_kd + ns, *s_lights = s_ks + ns;
+	uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds4 + 4 * ns + 1 + 2 * nl); // 4 wave counts + block base
+	const int tid = threadIdx.x;
+	for(int i = tid; i < ns; i += 256)
+	{
+		s_geom[i] = p.sph_geom[i];
+		s_amb[i] = p.sph_amb[i];
+		s_kd[i] = p.sph_kd[i];
+		s_ks[i] = p.sph_ks[i];
+	}
+	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
+	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	__syncthreads();
+	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl};
+
+	const int wave = tid >> 6, lane = tid & 63;
+	const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
+	const int x = blockIdx.x * 16 + lx;
+	const uint32_t orow = blockIdx.y * 16 + ly;
+	const uint32_t k = orow / p.tile_rows;
+	const uint32_t y = (p.first_tile + k * p.tile_stride) * p.tile_rows + (orow - k * p.tile_rows);
+	const bool valid = x < p.width && orow < p.out_rows && y < (uint32_t) p.height;
+	const uint32_t pixel = y * (uint32_t) p.width + (uint32_t) x;
+	const uint32_t out_pix = orow * (uint32_t) p.width + (uint32_t) x;
+
+	Counters cn{0, 0, 0};
+	f3 colour = mk3(0, 0, 0), co = mk3(0, 0, 0), N = mk3(0, 0, 1), kd = mk3(0, 0, 0);
+	bool hit = false;
+	if(valid)
+	{
+		f3 dir;
+		primary_ray(p, x, y, pixel, p.aa_index, dir);
+		cn.rays++;
+		const RayConst r = make_ray(p.cam_pos, dir);
+		float tmin;
+		const int sph = closest_sphere(sv, r, tmin);
+		if(sv.nt > 0 && any_triangle_closer(sv, r, tmin)) colour = mk3(0, 0, 0);
+		else if(sph < 0) colour = p.background;
+		else
+		{
+			hit = true;
+			cn.hits++;
+			const f3 P = p.cam_pos + dir * tmin;
+			N = normalize3(P - ld3(sv.geom[sph]));
+			colour = direct_light(sv, p, sph, P, N, cn);
+			co = add_scalar(P, 0.00001f);
+			kd = ld3(sv.kd[sph]);
+		}
+	}
+	// append the hits: wave-level ranks, one atomic per workgroup
+	const unsigned long long M = __ballot(hit);
+	if(lane == 0) s_cnt[wave] = (uint32_t) __popcll(M);
+	__syncthreads();
+	if(tid == 0)
+	{
+		const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+		s_cnt[4] = total ? atomicAdd(&p.qctr[0], total) : 0u;
+	}
+	__syncthreads();
+	if(hit)
+	{
+		uint32_t idx = s_cnt[4] + (uint32_t) lanes_below(M);
+		for(int wv = 0; wv < wave; wv++) idx += s_cnt[wv];
+		float4 *rec = p.parents + (size_t) idx * 4;
+		rec[0] = make_float4(co.x, co.y, co.z, N.x);
+		rec[1] = make_float4(N.y, N.z, colour.x, colour.y);
+		rec[2] = make_float4(colour.z, kd.x, kd.y, kd.z);
+		rec[3] = make_float4(__uint_as_float(pixel), __uint_as_float(out_pix), 0.0f, 0.0f);
+	}
+	else if(valid) emit_sample(p, out_pix, colour); // this sample of this pixel is final
+	if(p.counters)
+	{
+		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays);
+		if(lane == 0)
+		{
+			const uint32_t shard = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (uint32_t) wave) & (SKR_COUNTER_SHARDS - 1u);
+			unsigned long long *c4 = p.counters + 4u * shard;
+			atomicAdd(&c4[0], (unsigned long long) a);
+			atomicAdd(&c4[1], (unsigned long long) b);
+			atomicAdd(&c4[2], (unsigned long long) c);
+		}
+	}
+}
+
+// Persistent waves: pull groups of parents, stream their trees, finish their pixels.
+template <int DEPTH, int OCC>
+__global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
+	const int ns = p.n_spheres, nl = p.n_lights;
+	float4 *s_geom = lds4, *s_amb = lds4 + ns + 1, *s_kd = s_amb + ns, *s_ks = s_kd + ns, *s_lights = s_ks + ns;
+	const int tid = threadIdx.x;
+	for(int i = tid; i < ns; i += 256)
+	{
+		s_geom[i] = p.sph_geom[i];
+		s_amb[i] = p.sph_amb[i];
+		s_kd[i] = p.sph_kd[i];
+		s_ks[i] = p.sph_ks[i];
+	}
+	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
+	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	__syncthreads(); // the only workgroup barrier
+
+	const int wave = tid >> 6, lane = tid & 63;
+	using C = Cfg<OCC>;
+	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * C::WAVE_LDS_FLOATS;
+	Wave w;
+	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl};
+	w.p = &p;
+	w.slots = wbase;
+	w.lane = lane;
+	w.N = p.num_path_traces;
+	w.magicN = (uint32_t) (((1u << 24) + (uint32_t) (w.N > 0 ? w.N : 1) - 1u) / (uint32_t) (w.N > 0 ? w.N : 1));
+	{
+		const uint32_t pp = (uint32_t) ((w.N > 0 ? w.N : 1) + 1) >> 1;
+		w.magicPP = ((1u << 24) + pp - 1u) / pp;
+	}
+	w.aa = p.aa_index;
+	w.pdf = (float) (1 / 3.14159265358979323846);
+	w.s0_max = C::S0_MAX;
+	w.s1_max = C::S1_MAX;
+	w.sbase1 = C::REGION0_FLOATS;
+	w.q2_two_step = C::Q2_CAP < 63 + 128;
+	w.par0_max = C::PAR0_MAX;
+	w.aw_max = C::AW_MAX;
+	w.act_max = C::ACT_MAX;
+	w.par0_tbl = wbase + C::SLOT_FLOATS + (C::Q1_CAP + C::Q2_CAP) * QF;
+	Queue q1{wbase + C::SLOT_FLOATS, C::Q1_CAP, 0, 0}, q2{wbase + C::SLOT_FLOATS + C::Q1_CAP * QF, C::Q2_CAP, 0, 0};
+
+	const uint32_t n_parents = p.qctr[0];
+	const uint32_t G = (uint32_t) (w.s0_max / (w.N > 0 ? w.N : 1) < w.par0_max ? w.s0_max / (w.N > 0 ? w.N : 1) : w.par0_max);
+	const uint32_t n_groups = (G > 0) ? (n_parents + G - 1) / G : 0;
+	// groups handed out per atomic: one word serves ~88 atomics/us, so big queues are drained 4 groups at
+	// a time; small ones (one rank's share of a sharded frame) one at a time, or the last chunks decide the time
+	const uint32_t slots = gridDim.x * 4u;
+	// (measured with tools/time_shard.py: 4-group chunks lose 30 % on a 1/8 frame, 1-group pulls 7 % on a 1/2 frame)
+	const uint32_t CH = n_groups >= 32u * slots ? 4u : (n_groups >= 16u * slots ? 2u : 1u);
+	Counters cn{0, 0, 0};
+	STAMP_DECL;
+	uint32_t g = 0, g_end = 0;
+	for(;;)
+	{
+		if(g == g_end)
+		{
+			uint32_t g0 = 0;
+			if(lane == 0) g0 = atomicAdd(&p.qctr[1], CH);
+			g = (uint32_t) __builtin_amdgcn_readfirstlane((int) g0);
+			if(g >= n_groups) break;
+			g_end = g + CH < n_groups ? g + CH : n_groups;
+		}
+		const uint32_t base = g * G;
+		const int gp = (int) (n_parents - base < G ? n_parents - base : G);
+		f3 direct0 = mk3(0, 0, 0), kd0 = mk3(0, 0, 0);
+		uint32_t out_pix = 0;
+		if(lane < gp)
+		{ // record -> LDS parent table (co, N, pixel); direct colour, kd and the output index stay in this lane
+			const float4 *rec = p.parents + (size_t) (base + lane) * 4;
+			const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+			float *tb = const_cast<float *>(w.par0_tbl) + 8 * lane;
+			tb[0] = r0.x; tb[1] = r0.y; tb[2] = r0.z;
+			tb[3] = r0.w; tb[4] = r1.x; tb[5] = r1.y;
+			tb[6] = r3.x;
+			direct0 = mk3(r1.z, r1.w, r2.x);
+			kd0 = mk3(r2.y, r2.z, r2.w);
+			out_pix = __float_as_uint(r3.y);
+		}
+		wave_lds_fence();
+		run_group<DEPTH>(w, gp, q1, q2, cn STAMP_PASS);
+		if(lane < gp)
+		{ // raytrace.h:133 + :213
+			f3 total = sum_slots(w, 0, lane);
+			total = total / (float) w.N;
+			emit_sample(p, out_pix, (direct0 / (float) 3.14159265358979323846 + total * 2.0f) * kd0);
+		}
+		wave_lds_fence();
+		g++;
+	}
+	if(p.counters)
+	{
+		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays);
+		if(lane == 0)
+		{
+			const uint32_t shard = (blockIdx.x * 4u + (uint32_t) wave) & (SKR_COUNTER_SHARDS - 1u);
+			unsigned long long *c4 = p.counters + 4u * shard;
+			atomicAdd(&c4[0], (unsigned long long) a);
+			atomicAdd(&c4[1], (unsigned long long) b);
+			atomicAdd(&c4[2], (unsigned long long) c);
+		}
+	}
+}
+
+// AA only: image[y][x] /= g*g (main.cpp:165), then the quantiser (main.cpp:205).
+__global__ __launch_bounds__(256) void skr_resolve_kernel(const RenderParams p)
+{
+	const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+	const size_t n = (size_t) p.width * p.out_rows;
+	if(i >= n) return;
+	const uint32_t orow = (uint32_t) (i / (size_t) p.width);
+	const uint32_t k = orow / p.tile_rows;
+	const uint32_t y = (p.first_tile + k * p.tile_stride) * p.tile_rows + (orow - k * p.tile_rows);
+	if(y >= (uint32_t) p.height) return;
+	const float ns2 = (float) (p.grid_size * p.grid_size);
+	const f3 px = mk3(p.acc[3 * i], p.acc[3 * i + 1], p.acc[3 * i + 2]) / ns2;
+	if(p.rgbf)
+	{
+		p.rgbf[3 * i] = px.x;
+		p.rgbf[3 * i + 1] = px.y;
+		p.rgbf[3 * i + 2] = px.z;
+	}
+	if(p.rgb)
+	{
+		p.rgb[3 * i] = (unsigned char) quantise(px.x);
+		p.rgb[3 * i + 1] = (unsigned char) quantise(px.y);
+		p.rgb[3 * i + 2] = (unsigned char) quantise(px.z);
+	}
+}
+
 static size_t wave_block_lds(const RenderParams &p, int occ)
 {
 	const size_t per_wave = (occ == 3 ? Cfg<3>::WAVE_LDS_FLOATS : Cfg<2>::WAVE_LDS_FLOATS) * sizeof(float);
@@ -904,4 +1201,63 @@ hipError_t skr_launch_wave(const RenderParams &p_in, hipStream_t stream)
 		case 3: return occ3 ? launch_wave_depth<3, 3>(p, grid, lds, stream) : launch_wave_depth<3, 2>(p, grid, lds, stream);
 		default: return hipErrorInvalidValue;
 	}
+}
+
+// ---- parent-queue pipeline: host side ----
+// Used for --gillum trees (depth 2..3) unless SKR_PIPELINE=mega asks for the single megakernel.
+bool skr_queue_selected(const RenderParams &p)
+{
+	const char *e = getenv("SKR_PIPELINE");
+	if(e && !strcmp(e, "mega")) return false;
+	return skr_wave_supported(p) && p.monte_carlo && p.n_spheres > 0 && p.max_depth >= 2 && p.num_path_traces > 0;
+}
+
+// scratch the caller must provide (api.cpp allocates it once per renderer and keeps it)
+void skr_queue_scratch_bytes(const RenderParams &p, size_t *parent_bytes, size_t *acc_bytes)
+{
+	const size_t pixels = (size_t) p.width * p.out_rows;
+	*parent_bytes = pixels * 64;
+	*acc_bytes = p.grid_size > 0 ? pixels * 12 : 0;
+}
+
+template <int D, int OCC>
+static hipError_t launch_gi(const RenderParams &p, size_t lds, hipStream_t stream)
+{
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(skr_gi_kernel<D, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+	if(e != hipSuccess) return e;
+	const dim3 grid(256u * (uint32_t) OCC); // every workgroup resident: 256 CUs x OCC workgroups of 4 waves
+	hipLaunchKernelGGL((skr_gi_kernel<D, OCC>), grid, dim3(256), lds, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t skr_launch_queue(const RenderParams &p_in, hipStream_t stream, const SkrTimingHook *hook)
+{
+	RenderParams p = p_in;
+	const int nsamp = p.grid_size > 0 ? p.grid_size * p.grid_size : 1;
+	const size_t lds1 = ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 32;
+	const size_t lds2 = skr_wave_lds_bytes(p);
+	const bool occ3 = wave_occ_for(p) == 3;
+	const dim3 grid1((p.width + 15) / 16, (p.out_rows + 15) / 16);
+	for(int s = 0; s < nsamp; s++)
+	{
+		p.aa_index = (uint32_t) s;
+		hipError_t e = hipMemsetAsync(p.qctr, 0, 2 * sizeof(uint32_t), stream);
+		if(e != hipSuccess) return e;
+		hipLaunchKernelGGL(skr_primary_kernel, grid1, dim3(256), lds1, stream, p);
+		e = hipGetLastError();
+		if(e != hipSuccess) return e;
+		// the GI kernel is the dominant one: time it alone (last sample's launch when there are several)
+		if(hook && hook->start && s == nsamp - 1) (void) hipEventRecord(hook->start, stream);
+		if(p.max_depth == 2) e = occ3 ? launch_gi<2, 3>(p, lds2, stream) : launch_gi<2, 2>(p, lds2, stream);
+		else e = occ3 ? launch_gi<3, 3>(p, lds2, stream) : launch_gi<3, 2>(p, lds2, stream);
+		if(hook && hook->stop && s == nsamp - 1) (void) hipEventRecord(hook->stop, stream);
+		if(e != hipSuccess) return e;
+	}
+	if(p.grid_size > 0)
+	{
+		const size_t n = (size_t) p.width * p.out_rows;
+		hipLaunchKernelGGL(skr_resolve_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, p);
+		return hipGetLastError();
+	}
+	return hipSuccess;
 }
