@@ -236,3 +236,17 @@ def test_synthetic_scenes_match_oracle(gpu, oracle, tmp_path, n_spheres, n_light
     compare(rgb.cpu().numpy(), rgbf.cpu().numpy(), o_rgb, o_f, "synthetic %d/%d/%d" % (n_spheres, n_lights, n_tris))
     cnt = r.counters()
     assert cnt["radiance_rays"] == int(st[0]) and cnt["sphere_hits"] == int(st[1])
+
+
+def test_full_size_config5_rows_against_oracle(gpu, oracle):
+    """BASELINE config 5 at its real size (3840x2160 --gillum 64 --jsample 5 --shadow, ~9e10 radiance rays):
+    whole frame on the GPU (25 AA samples through the parent-queue pipeline), two row bands bit for bit
+    against the oracle."""
+    w, h = 3840, 2160
+    kw = dict(gillum=64, jsample=5, shadow=True, seed=5)
+    g_rgb, g_f, cnt = gpu_render("spheres2.scn", w, h, **kw)
+    for y0, y1 in ((1399, 1400), (2158, 2159)):
+        o_rgb, o_f, _ = oracle.render(scene_path("spheres2.scn"), w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED,
+                                      want_float=True, y0=y0, y1=y1, **kw)
+        compare(g_rgb[y0:y1], g_f[y0:y1], o_rgb, o_f, "4K rows %d-%d" % (y0, y1))
+    assert cnt["radiance_rays"] > 25 * w * h
