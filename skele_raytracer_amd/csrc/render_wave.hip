@@ -1074,6 +1074,7 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 			out_pix = __float_as_uint(r3.y);
 		}
 		wave_lds_fence();
+		STAMP(0);
 		run_group<DEPTH>(w, gp, q1, q2, cn STAMP_PASS);
 		if(lane < gp)
 		{ // raytrace.h:133 + :213
@@ -1082,8 +1083,13 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 			emit_sample(p, out_pix, (direct0 / (float) 3.14159265358979323846 + total * 2.0f) * kd0);
 		}
 		wave_lds_fence();
+		STAMP(7);
 		g++;
 	}
+#if defined(SKR_STAMPS) && SKR_STAMPS
+	if(p.counters && lane == 0)
+		for(int k = 0; k < 8; k++) atomicAdd(&p.counters[4u * SKR_COUNTER_SHARDS + k], st_acc[k]);
+#endif
 	if(p.counters)
 	{
 		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays);
