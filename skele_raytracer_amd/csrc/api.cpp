@@ -247,6 +247,7 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 			r->acc_cap = need_acc;
 		}
 		p.parents = reinterpret_cast<float4 *>(r->d_parents);
+		p.slot0_scratch = reinterpret_cast<float *>(reinterpret_cast<char *>(r->d_parents) + (size_t) p.width * p.out_rows * 64);
 		p.acc = r->d_acc;
 	}
 	if(skr_render_lds_bytes(p) > (size_t) r->lds_limit)

@@ -32,6 +32,7 @@ struct RenderParams {
 	// parent-queue pipeline (render_wave.hip: skr_primary_kernel -> skr_gi_kernel -> skr_resolve_kernel)
 	float4 *parents;    // 4 x float4 per primary hit: co.xyz N.x | N.yz direct.xy | direct.z kd.xyz | pixel, out_pix, -, -
 	uint32_t *qctr;     // [0] number of parents appended, [1] next group to hand out
+	float *slot0_scratch; // per-wave level-1 contribution slots of the GI kernel (behind the parent records)
 	float *acc;         // float3 per output pixel: the running `image[y][x] += shade(...)` of main.cpp:162 (AA only)
 	uint32_t aa_index;  // which AA sample this launch traces
 };

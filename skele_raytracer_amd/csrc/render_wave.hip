@@ -35,7 +35,9 @@ namespace {
 //   Cfg<3>: 12.5 KB of LDS per wave, <= 168 VGPRs  — best for gillum <= 32 (more waves hide latency)
 //   Cfg<2>: 17.5 KB of LDS per wave, <= 256 VGPRs  — bigger slot windows, best for large gillum
 constexpr int QF = 8;        // dwords per queue record: d.xyz, b, D, packed ids, slot, r1
-template <int OCC>
+// GLOBAL0: the level-1 contribution slots live in a per-wave HBM scratch (L2-resident) instead of LDS — the
+// GI kernel of the parent-queue pipeline: groups of up to 32 parents keep the activation batches full.
+template <int OCC, bool GLOBAL0 = false>
 struct Cfg {
 	static constexpr int S0_MAX = (OCC >= 3) ? 128 : 256; // level-1 contribution slots of one parent group (G * N <= S0_MAX)
 	static constexpr int S1_MAX = (OCC >= 3) ? 256 : 512; // leaf contribution slots of one window          (AW * N <= S1_MAX)
@@ -45,8 +47,8 @@ struct Cfg {
 	// level-1 hits are turned into parents ACT_MAX at a time; the ring holds <= ACT_MAX-1 left over + 64 new
 	static constexpr int ACT_MAX = (OCC >= 3) ? 56 : 64;
 	static constexpr int Q1_CAP = ACT_MAX + 64;
-	static constexpr int PAR0_MAX = (OCC >= 3) ? 8 : 16;  // level-1 parents per group (G)
-	static constexpr int REGION0_FLOATS = S0_MAX * 3 + PAR0_MAX; // + one pad dword per parent (bank spread)
+	static constexpr int PAR0_MAX = GLOBAL0 ? 32 : ((OCC >= 3) ? 8 : 16); // level-1 parents per group (G)
+	static constexpr int REGION0_FLOATS = GLOBAL0 ? 0 : S0_MAX * 3 + PAR0_MAX; // + one pad dword per parent (bank spread)
 	static constexpr int AW_MAX = (OCC >= 3) ? 16 : 32;          // parents per leaf-slot window
 	static constexpr int REGION1_FLOATS = S1_MAX * 3 + AW_MAX;
 	static constexpr int SLOT_FLOATS = REGION0_FLOATS + REGION1_FLOATS;
@@ -54,7 +56,7 @@ struct Cfg {
 	// level-1 parents of the current group live in LDS (8 dwords each), not in registers: they are only
 	// touched once per round, and holding them in VGPRs through the leaf phases cost occupancy
 	static constexpr int WAVE_LDS_FLOATS = SLOT_FLOATS + (Q1_CAP + Q2_CAP) * QF + PAR0_MAX * 8;
-	static_assert(REGION1_FLOATS >= 64 + PAR0_MAX * 3 + 48, "aliases must fit");
+	static_assert(REGION1_FLOATS >= 64 + 16 * 3 + 48, "aliases must fit");
 };
 constexpr int GILLUM_MAX = 256; // child index is 8 bits in HitRec.ids; Cfg<2>::S0_MAX
 
@@ -78,12 +80,20 @@ SKR_DEV void wave_lds_fence()
 	__builtin_amdgcn_wave_barrier();
 }
 
+// Slot offsets with this bit address the wave's HBM scratch instead of its LDS area.  The scratch is
+// written and read by lanes of ONE wave only; sc1 (agent-scope relaxed) accesses keep it out of the
+// CU's L1, so after the wave's own vmcnt(0) a load sees the store.
+constexpr int SLOT_GLOBAL = 0x40000000;
+
 SKR_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 SKR_DEV f3 shfl3(f3 v, int src) { return mk3(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64)); }
 SKR_DEV int lanes_below(unsigned long long m)
 {
 	return (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
 }
+
+SKR_DEV void g_store(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SKR_DEV float g_load(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct Queue { // ring of sphere-hit records in LDS, SoA by field; head/count are wave-uniform
 	float *base;
@@ -163,8 +173,27 @@ struct Wave {
 	float pdf;
 	int s0_max, s1_max, sbase1, par0_max, aw_max, act_max; // Cfg<OCC> of this kernel instance
 	const float *par0_tbl;                // level-1 parents of the current group: co.xyz, N.xyz, pixel, -
+	float *slot0_g;                       // != nullptr: level-1 slots of parent k, child i at slot0_g[k*3N + 3i] (HBM scratch)
 	bool q2_two_step;           // the leaf ring cannot take both halves of a pair round at once
 };
+
+SKR_DEV void slot_store(const Wave &w, int slot, f3 v)
+{
+	if(slot & SLOT_GLOBAL)
+	{
+		float *g = w.slot0_g + (slot & ~SLOT_GLOBAL);
+		g_store(g, v.x);
+		g_store(g + 1, v.y);
+		g_store(g + 2, v.z);
+	}
+	else
+	{
+		float *s = w.slots + slot;
+		s[0] = v.x;
+		s[1] = v.y;
+		s[2] = v.z;
+	}
+}
 
 // Where a round's parents live: registers of lanes (shuffle) or the wave's LDS table.
 struct ParSrc {
@@ -256,7 +285,8 @@ SKR_DEV void child_round(const Wave &w, const ParSrc &par, int kbase, int np, in
 	h.d = mk3(0, 0, 0);
 	h.b = h.D = h.r1 = 0.0f;
 	h.ids = 0;
-	h.slot = sbase + k * (3 * w.N + 1) + 3 * i;
+	// level-1 rounds (sbase 0) of the GI kernel deposit into the HBM scratch
+	h.slot = (sbase == 0 && w.slot0_g) ? (SLOT_GLOBAL | (k * 3 * w.N + 3 * i)) : sbase + k * (3 * w.N + 1) + 3 * i;
 	bool hit = false;
 	if(valid)
 	{
@@ -279,11 +309,7 @@ SKR_DEV void child_round(const Wave &w, const ParSrc &par, int kbase, int np, in
 		if(tri || sph < 0)
 		{ // raytrace.h:189-192 / :221-224, then :130: total += (r1 * colour) / pdf
 			const f3 colour = tri ? mk3(0, 0, 0) : w.p->background;
-			const f3 contrib = (colour * r1) / w.pdf;
-			float *s = w.slots + h.slot;
-			s[0] = contrib.x;
-			s[1] = contrib.y;
-			s[2] = contrib.z;
+			slot_store(w, h.slot, (colour * r1) / w.pdf);
 		}
 		else
 		{
@@ -462,11 +488,7 @@ SKR_DEV void shade_leaf_batch(const Wave &w, Queue &q, const ParSrc &par, int m,
 		const f3 direct = direct_light(w.sv, *w.p, sph, P, N, cn);
 		const f3 total = mk3(0, 0, 0) / (float) w.N;
 		const f3 colour = (direct / (float) 3.14159265358979323846 + total * 2.0f) * ld3(w.sv.kd[sph]);
-		const f3 contrib = (colour * h.r1) / w.pdf;
-		float *s = w.slots + h.slot;
-		s[0] = contrib.x;
-		s[1] = contrib.y;
-		s[2] = contrib.z;
+		slot_store(w, h.slot, (colour * h.r1) / w.pdf);
 	}
 	q_drop(q, m);
 	wave_lds_fence();
@@ -558,11 +580,7 @@ SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, int m, Cou
 			f3 total = sum_slots(w, sbase1, w.lane - w0);
 			total = total / (float) w.N;
 			const f3 colour = (direct1 / (float) 3.14159265358979323846 + total * 2.0f) * ld3(w.sv.kd[sph1]);
-			const f3 contrib = (colour * h.r1) / w.pdf;
-			float *s = w.slots + h.slot;
-			s[0] = contrib.x;
-			s[1] = contrib.y;
-			s[2] = contrib.z;
+			slot_store(w, h.slot, (colour * h.r1) / w.pdf);
 		}
 		wave_lds_fence();
 		STAMP(5);
@@ -724,6 +742,7 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 	w.aw_max = C::AW_MAX;
 	w.act_max = C::ACT_MAX;
 	w.par0_tbl = wbase + C::SLOT_FLOATS + (C::Q1_CAP + C::Q2_CAP) * QF;
+	w.slot0_g = nullptr;
 	Queue q1{wbase + C::SLOT_FLOATS, C::Q1_CAP, 0, 0}, q2{wbase + C::SLOT_FLOATS + C::Q1_CAP * QF, C::Q2_CAP, 0, 0};
 	int *lane_tbl = reinterpret_cast<int *>(wbase + C::REGION0_FLOATS); // aliases of the leaf slot region, see Cfg
 	float *gres = wbase + C::REGION0_FLOATS + 64;
@@ -1011,7 +1030,7 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 	__syncthreads(); // the only workgroup barrier
 
 	const int wave = tid >> 6, lane = tid & 63;
-	using C = Cfg<OCC>;
+	using C = Cfg<OCC, true>;
 	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * C::WAVE_LDS_FLOATS;
 	Wave w;
 	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl};
@@ -1034,16 +1053,20 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 	w.aw_max = C::AW_MAX;
 	w.act_max = C::ACT_MAX;
 	w.par0_tbl = wbase + C::SLOT_FLOATS + (C::Q1_CAP + C::Q2_CAP) * QF;
+	// this wave's private level-1 slot scratch: PAR0_MAX parents x N children x float3
+	w.slot0_g = p.slot0_scratch + (size_t) (blockIdx.x * 4u + (uint32_t) wave) * (size_t) (C::PAR0_MAX * 3) * (size_t) (w.N > 0 ? w.N : 1);
 	Queue q1{wbase + C::SLOT_FLOATS, C::Q1_CAP, 0, 0}, q2{wbase + C::SLOT_FLOATS + C::Q1_CAP * QF, C::Q2_CAP, 0, 0};
 
 	const uint32_t n_parents = p.qctr[0];
-	const uint32_t G = (uint32_t) (w.s0_max / (w.N > 0 ? w.N : 1) < w.par0_max ? w.s0_max / (w.N > 0 ? w.N : 1) : w.par0_max);
-	const uint32_t n_groups = (G > 0) ? (n_parents + G - 1) / G : 0;
-	// groups handed out per atomic: one word serves ~88 atomics/us, so big queues are drained 4 groups at
-	// a time; small ones (one rank's share of a sharded frame) one at a time, or the last chunks decide the time
+	// parents per group: as many as keep ~8 groups per wave slot, between 8 and the table's 32 (big groups
+	// fill the 56-wide activation batches; small queues need small groups to balance)
 	const uint32_t slots = gridDim.x * 4u;
-	// (measured with tools/time_shard.py: 4-group chunks lose 30 % on a 1/8 frame, 1-group pulls 7 % on a 1/2 frame)
-	const uint32_t CH = n_groups >= 32u * slots ? 4u : (n_groups >= 16u * slots ? 2u : 1u);
+	uint32_t G = (n_parents / (slots * 8u)) & ~7u;
+	G = G < 8u ? 8u : (G > (uint32_t) w.par0_max ? (uint32_t) w.par0_max : G);
+	const uint32_t n_groups = (n_parents + G - 1) / G;
+	// one group per atomic: with G adapting to the queue there are at most ~8 pulls per wave slot and
+	// frame, far below what one word sustains (~88 atomics/us)
+	const uint32_t CH = 1u;
 	Counters cn{0, 0, 0};
 	STAMP_DECL;
 	uint32_t g = 0, g_end = 0;
@@ -1076,9 +1099,13 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 		wave_lds_fence();
 		STAMP(0);
 		run_group<DEPTH>(w, gp, q1, q2, cn STAMP_PASS);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's sc1 slot stores have reached L2
+		__builtin_amdgcn_wave_barrier();
 		if(lane < gp)
-		{ // raytrace.h:133 + :213
-			f3 total = sum_slots(w, 0, lane);
+		{ // raytrace.h:133 + :213: the N terms strictly in child order
+			const float *s = w.slot0_g + lane * 3 * w.N;
+			f3 total = mk3(0, 0, 0);
+			for(int i = 0; i < w.N; i++) total = total + mk3(g_load(s + 3 * i), g_load(s + 3 * i + 1), g_load(s + 3 * i + 2));
 			total = total / (float) w.N;
 			emit_sample(p, out_pix, (direct0 / (float) 3.14159265358979323846 + total * 2.0f) * kd0);
 		}
@@ -1130,9 +1157,10 @@ __global__ __launch_bounds__(256) void skr_resolve_kernel(const RenderParams p)
 	}
 }
 
-static size_t wave_block_lds(const RenderParams &p, int occ)
+static size_t wave_block_lds(const RenderParams &p, int occ, bool global0 = false)
 {
-	const size_t per_wave = (occ == 3 ? Cfg<3>::WAVE_LDS_FLOATS : Cfg<2>::WAVE_LDS_FLOATS) * sizeof(float);
+	const size_t per_wave = (global0 ? (occ == 3 ? Cfg<3, true>::WAVE_LDS_FLOATS : Cfg<2, true>::WAVE_LDS_FLOATS)
+									  : (occ == 3 ? Cfg<3>::WAVE_LDS_FLOATS : Cfg<2>::WAVE_LDS_FLOATS)) * sizeof(float);
 	return ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 4 * per_wave;
 }
 
@@ -1222,7 +1250,8 @@ bool skr_queue_selected(const RenderParams &p)
 void skr_queue_scratch_bytes(const RenderParams &p, size_t *parent_bytes, size_t *acc_bytes)
 {
 	const size_t pixels = (size_t) p.width * p.out_rows;
-	*parent_bytes = pixels * 64;
+	// parent records, then the GI kernel's per-wave level-1 slot scratch (768 workgroups x 4 waves x 32 parents x N x float3)
+	*parent_bytes = pixels * 64 + (size_t) 256 * 3 * 4 * 32 * 3 * sizeof(float) * (size_t) (p.num_path_traces > 0 ? p.num_path_traces : 1);
 	*acc_bytes = p.grid_size > 0 ? pixels * 12 : 0;
 }
 
@@ -1241,8 +1270,8 @@ hipError_t skr_launch_queue(const RenderParams &p_in, hipStream_t stream, const 
 	RenderParams p = p_in;
 	const int nsamp = p.grid_size > 0 ? p.grid_size * p.grid_size : 1;
 	const size_t lds1 = ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 32;
-	const size_t lds2 = skr_wave_lds_bytes(p);
 	const bool occ3 = wave_occ_for(p) == 3;
+	const size_t lds2 = wave_block_lds(p, occ3 ? 3 : 2, true);
 	const dim3 grid1((p.width + 15) / 16, (p.out_rows + 15) / 16);
 	for(int s = 0; s < nsamp; s++)
 	{
