@@ -47,7 +47,7 @@ struct Cfg {
 	// level-1 hits are turned into parents ACT_MAX at a time; the ring holds <= ACT_MAX-1 left over + 64 new
 	static constexpr int ACT_MAX = (OCC >= 3) ? 56 : 64;
 	static constexpr int Q1_CAP = ACT_MAX + 64;
-	static constexpr int PAR0_MAX = GLOBAL0 ? 32 : ((OCC >= 3) ? 8 : 16); // level-1 parents per group (G)
+	static constexpr int PAR0_MAX = GLOBAL0 ? 24 : ((OCC >= 3) ? 8 : 16); // level-1 parents per group (G)
 	static constexpr int REGION0_FLOATS = GLOBAL0 ? 0 : S0_MAX * 3 + PAR0_MAX; // + one pad dword per parent (bank spread)
 	static constexpr int AW_MAX = (OCC >= 3) ? 16 : 32;          // parents per leaf-slot window
 	static constexpr int REGION1_FLOATS = S1_MAX * 3 + AW_MAX;
@@ -81,8 +81,10 @@ SKR_DEV void wave_lds_fence()
 }
 
 // Slot offsets with this bit address the wave's HBM scratch instead of its LDS area.  The scratch is
-// written and read by lanes of ONE wave only; sc1 (agent-scope relaxed) accesses keep it out of the
-// CU's L1, so after the wave's own vmcnt(0) a load sees the store.
+// written and read by lanes of ONE wave only: workgroup-scope accesses (plain global loads/stores; the
+// CU's L1 is coherent for its own waves) ordered by the wave's own vmcnt(0).  Plain stores stay in the
+// XCD's write-back L2, and a wave reuses its few KB for every group, so almost none of it reaches HBM
+// (sc1 write-through stores measured 0.85 GB per frame here).
 constexpr int SLOT_GLOBAL = 0x40000000;
 
 SKR_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -92,8 +94,8 @@ SKR_DEV int lanes_below(unsigned long long m)
 	return (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
 }
 
-SKR_DEV void g_store(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-SKR_DEV float g_load(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SKR_DEV void g_store(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+SKR_DEV float g_load(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 struct Queue { // ring of sphere-hit records in LDS, SoA by field; head/count are wave-uniform
 	float *base;
@@ -1087,7 +1089,13 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 		if(lane < gp)
 		{ // record -> LDS parent table (co, N, pixel); direct colour, kd and the output index stay in this lane
 			const float4 *rec = p.parents + (size_t) (base + lane) * 4;
-			const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+			// streamed once: non-temporal, so the records do not push the waves' slot scratch out of L2
+			typedef float v4f __attribute__((ext_vector_type(4)));
+			const v4f *rv = reinterpret_cast<const v4f *>(rec);
+			const v4f a0 = __builtin_nontemporal_load(&rv[0]), a1 = __builtin_nontemporal_load(&rv[1]),
+					  a2 = __builtin_nontemporal_load(&rv[2]), a3 = __builtin_nontemporal_load(&rv[3]);
+			const float4 r0 = make_float4(a0.x, a0.y, a0.z, a0.w), r1 = make_float4(a1.x, a1.y, a1.z, a1.w),
+						 r2 = make_float4(a2.x, a2.y, a2.z, a2.w), r3 = make_float4(a3.x, a3.y, a3.z, a3.w);
 			float *tb = const_cast<float *>(w.par0_tbl) + 8 * lane;
 			tb[0] = r0.x; tb[1] = r0.y; tb[2] = r0.z;
 			tb[3] = r0.w; tb[4] = r1.x; tb[5] = r1.y;
@@ -1099,7 +1107,7 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 		wave_lds_fence();
 		STAMP(0);
 		run_group<DEPTH>(w, gp, q1, q2, cn STAMP_PASS);
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's sc1 slot stores have reached L2
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's slot stores are complete
 		__builtin_amdgcn_wave_barrier();
 		if(lane < gp)
 		{ // raytrace.h:133 + :213: the N terms strictly in child order
