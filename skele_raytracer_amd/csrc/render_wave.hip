@@ -1082,13 +1082,19 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 			if(g >= n_groups) break;
 			g_end = g + CH < n_groups ? g + CH : n_groups;
 		}
-		const uint32_t base = g * G;
-		const int gp = (int) (n_parents - base < G ? n_parents - base : G);
+		// A group is G consecutive queue entries (screen neighbours: coherent rays, 6 % faster on a full
+		// frame) — unless there are fewer than ~12 groups per wave slot: then one run of deep ground pixels
+		// (8 x 273 rays) decides the frame time, and group g takes parents g, g + n_groups, g + 2 n_groups, ...
+		// instead, which mixes deep and shallow trees (1/8 frame: 0.525 -> 0.486 ms).
+		const bool strided = n_groups < 12u * slots;
+		const uint32_t first = strided ? g : g * G, step = strided ? n_groups : 1u;
+		const uint32_t avail = strided ? (n_parents - 1u - g) / n_groups + 1u : n_parents - first;
+		const int gp = (int) (avail < G ? avail : G);
 		f3 direct0 = mk3(0, 0, 0), kd0 = mk3(0, 0, 0);
 		uint32_t out_pix = 0;
 		if(lane < gp)
 		{ // record -> LDS parent table (co, N, pixel); direct colour, kd and the output index stay in this lane
-			const float4 *rec = p.parents + (size_t) (base + lane) * 4;
+			const float4 *rec = p.parents + (size_t) (first + (uint32_t) lane * step) * 4;
 			// streamed once: non-temporal, so the records do not push the waves' slot scratch out of L2
 			typedef float v4f __attribute__((ext_vector_type(4)));
 			const v4f *rv = reinterpret_cast<const v4f *>(rec);
