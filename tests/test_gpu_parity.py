@@ -250,3 +250,35 @@ def test_full_size_config5_rows_against_oracle(gpu, oracle):
                                       want_float=True, y0=y0, y1=y1, **kw)
         compare(g_rgb[y0:y1], g_f[y0:y1], o_rgb, o_f, "4K rows %d-%d" % (y0, y1))
     assert cnt["radiance_rays"] > 25 * w * h
+
+
+def test_all_kernel_variants_agree(gpu, monkeypatch):
+    """The product has one arithmetic spec and several schedules: the parent-queue pipeline (default for
+    --gillum), the single wave-streaming megakernel with each per-wave tile shape and each LDS/VGPR budget,
+    and the per-pixel kernel.  Every one of them must produce the same bits and the same ray counts."""
+    w, h = 176, 99
+    opt = skr.Options(w, h, gillum=8, shadow=True, seed=31)
+    r = renderer("spheres2.scn")
+
+    def run(env):
+        for k in ("SKR_PIPELINE", "SKR_KERNEL", "SKR_OCC", "SKR_TILE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r.counters(reset=True)
+        rgb, rgbf = r.render(opt, want_float=True)
+        gpu.cuda.synchronize()
+        return rgb.cpu().numpy(), rgbf.cpu().numpy().view(np.uint32), r.counters(), r.kernel_variant()
+
+    base = run({})
+    assert base[3] == "parent_queue_v3"
+    seen = {base[3]}
+    for env in ({"SKR_PIPELINE": "mega"}, {"SKR_PIPELINE": "mega", "SKR_TILE": "64"}, {"SKR_PIPELINE": "mega", "SKR_TILE": "16"},
+                {"SKR_PIPELINE": "mega", "SKR_OCC": "2"}, {"SKR_OCC": "2"}, {"SKR_OCC": "3"}, {"SKR_KERNEL": "v1"}):
+        got = run(env)
+        seen.add(got[3])
+        assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
+        assert got[2] == base[2], env
+    assert seen == {"parent_queue_v3", "wave_streaming_v2", "lane_per_pixel_dfs_v1f"}
+    for k in ("SKR_PIPELINE", "SKR_KERNEL", "SKR_OCC", "SKR_TILE"):
+        monkeypatch.delenv(k, raising=False)
