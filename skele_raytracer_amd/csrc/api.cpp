@@ -35,7 +35,8 @@ struct skr_renderer {
 	int device = 0;
 	skr_scene_info info{};
 	float4 *d_blob = nullptr; // one allocation: geom | amb | kd | ks | lights | tris
-	size_t off_amb = 0, off_kd = 0, off_ks = 0, off_lights = 0, off_tris = 0;
+	size_t off_amb = 0, off_kd = 0, off_ks = 0, off_lights = 0, off_tris = 0, off_chunks = 0;
+	int n_chunks = 0;
 	unsigned long long *d_counters = nullptr;
 	int lds_limit = 0;
 	// scratch of the parent-queue pipeline, grown on demand and kept
@@ -90,7 +91,10 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	r->off_ks = 3 * ns;
 	r->off_lights = 4 * ns;
 	r->off_tris = 4 * ns + nl2;
-	const size_t total = 4 * ns + nl2 + nt3;
+	const size_t nch = scene->tri_chunks.size();
+	r->off_chunks = 4 * ns + nl2 + nt3;
+	r->n_chunks = nch ? (int) nch - 1 : 0; // the last entry is the prefetch pad
+	const size_t total = 4 * ns + nl2 + nt3 + nch;
 	std::vector<skr_f4> blob(total > 0 ? total : 1);
 	if(ns)
 	{
@@ -101,6 +105,7 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	}
 	if(nl2) memcpy(&blob[r->off_lights], scene->lights.data(), nl2 * 16);
 	if(nt3) memcpy(&blob[r->off_tris], scene->tris.data(), nt3 * 16);
+	if(nch) memcpy(&blob[r->off_chunks], scene->tri_chunks.data(), nch * 16);
 	hipError_t e = hipMalloc((void **) &r->d_blob, blob.size() * 16);
 	if(e == hipSuccess) e = hipMemcpy(r->d_blob, blob.data(), blob.size() * 16, hipMemcpyHostToDevice);
 	if(e == hipSuccess) e = hipMalloc((void **) &r->d_counters, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long));
@@ -215,6 +220,13 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.sph_ks = r->d_blob + r->off_ks;
 	p.lights = r->d_blob + r->off_lights;
 	p.tris = r->d_blob + r->off_tris;
+	p.tri_chunks = r->d_blob + r->off_chunks;
+	{ // the chunk spheres are valid for |d| <= SKR_CULL_DMAX: primary directions are dir + u right + v up, GI ones stay below 4
+		auto len3 = [](const float *v) { return std::sqrt((double) v[0] * v[0] + (double) v[1] * v[1] + (double) v[2] * v[2]); };
+		const double umax = std::fabs((double) p.angle * p.aspect) * 1.001, vmax = std::fabs((double) p.angle) * 1.001;
+		const double dmax = len3(c + 3) + umax * len3(c + 9) + vmax * len3(c + 6);
+		p.n_tri_chunks = (dmax < SKR_CULL_DMAX && !getenv("SKR_NO_CULL")) ? r->n_chunks : 0;
+	}
 	p.monte_carlo = opt->monte_carlo ? 1 : 0;
 	p.num_path_traces = opt->num_path_traces;
 	p.grid_size = opt->grid_size;

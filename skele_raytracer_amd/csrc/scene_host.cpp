@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <cmath>
 #include <fstream>
 
 static thread_local char g_err[512] = "";
@@ -76,6 +78,80 @@ void skr_scene::finalize()
 		tris[3 * i] = {t[0], t[1], t[2], 0.0f};
 		tris[3 * i + 1] = {t[3] - t[0], t[4] - t[1], t[5] - t[2], 0.0f};
 		tris[3 * i + 2] = {t[6] - t[0], t[7] - t[1], t[8] - t[2], 0.0f};
+	}
+	build_triangle_chunks();
+}
+
+// Exact-preserving culling data for the triangle walk (DESIGN.md "Triangle chunks").
+//
+// In exact arithmetic utils.h:181-213 accepts the line o + t d iff it meets the plane of the triangle in
+// X = v0 + a e1 + b e2 with a in [-1, 0] (the reference's u carries a flipped sign), b >= 0, b - a <= 1,
+// i.e. inside the triangle (v0, v0 - e1, v0 + e2), and |det| >= 1e-5.  In binary32 the computed u, v differ
+// from the exact ones by at most
+//     eta_u <= 7 eps |d| |e2| (|T| + 1.01 |e1|) / 0.99e-5,   eta_v <= 7 eps |d| |e1| (|T| + 1.01 |e2|) / 0.99e-5
+// (eps = 2^-24; three-term dot products and 2x2 cross terms of rounded inputs, divided by a determinant that
+// the test itself bounds away from zero), so an accepted line passes within eta_u |e1| + eta_v |e2| of that
+// triangle.  Every chunk gets a sphere around its triangles' accept regions, inflated by 16x that slack
+// (evaluated for |d| <= SKR_CULL_DMAX and the farthest possible ray origin: camera or any sphere surface) plus
+// an absolute term for the rounding of the device's own line-sphere test.  Where the slack is not small the
+// radius becomes infinite and the chunk is simply never culled.
+void skr_scene::build_triangle_chunks()
+{
+	const int nt = info.n_triangles;
+	tri_chunks.clear();
+	if(nt == 0) return;
+	const double eps = 5.9604644775390625e-08; // 2^-24
+	auto norm = [](double x, double y, double z) { return std::sqrt(x * x + y * y + z * z); };
+	// where rays can start: the camera, or on a sphere (GI children, raytrace.h:128)
+	struct Org { double x, y, z, r; };
+	std::vector<Org> orgs;
+	orgs.push_back({info.camera[0], info.camera[1], info.camera[2], 1e-3});
+	for(int i = 0; i < info.n_spheres; i++)
+	{
+		const float *s = &raw_spheres[(size_t) i * 14];
+		orgs.push_back({s[0], s[1], s[2], std::fabs((double) s[3]) + 1e-3});
+	}
+	const int nc = (nt + SKR_TRI_CHUNK - 1) / SKR_TRI_CHUNK;
+	tri_chunks.assign((size_t) nc + 1, skr_f4{0.0f, 0.0f, 0.0f, INFINITY}); // + pad entry
+	for(int c = 0; c < nc; c++)
+	{
+		const int i0 = c * SKR_TRI_CHUNK, i1 = std::min(nt, i0 + SKR_TRI_CHUNK);
+		double cx = 0, cy = 0, cz = 0;
+		int np = 0;
+		std::vector<double> pts;
+		double slack = 0, mag = 0;
+		bool unbounded = false;
+		for(int i = i0; i < i1; i++)
+		{
+			const skr_f4 v0 = tris[3 * i], e1 = tris[3 * i + 1], e2 = tris[3 * i + 2];
+			const double P[3][3] = {{v0.x, v0.y, v0.z}, {(double) v0.x - e1.x, (double) v0.y - e1.y, (double) v0.z - e1.z},
+									{(double) v0.x + e2.x, (double) v0.y + e2.y, (double) v0.z + e2.z}};
+			for(auto &q : P)
+			{
+				pts.insert(pts.end(), q, q + 3);
+				cx += q[0]; cy += q[1]; cz += q[2];
+				np++;
+				mag = std::max(mag, std::max(std::fabs(q[0]), std::max(std::fabs(q[1]), std::fabs(q[2]))));
+			}
+			double tmax = 0;
+			for(const Org &o : orgs) tmax = std::max(tmax, norm(o.x - v0.x, o.y - v0.y, o.z - v0.z) + o.r);
+			const double l1 = norm(e1.x, e1.y, e1.z), l2 = norm(e2.x, e2.y, e2.z);
+			const double eta_u = 7 * eps * SKR_CULL_DMAX * l2 * (tmax + 1.01 * l1) / 0.99e-5;
+			const double eta_v = 7 * eps * SKR_CULL_DMAX * l1 * (tmax + 1.01 * l2) / 0.99e-5;
+			const double rho_det = 7 * eps * SKR_CULL_DMAX * l1 * l2 / 1e-5; // relative error of the computed determinant at the 1e-5 threshold
+			if(!(eta_u < 0.25) || !(eta_v < 0.25) || !(rho_det < 0.01)) unbounded = true;
+			slack = std::max(slack, 16 * (eta_u * l1 + eta_v * l2));
+			mag = std::max(mag, tmax);
+		}
+		cx /= np; cy /= np; cz /= np;
+		double rad = 0;
+		for(int k = 0; k < np; k++) rad = std::max(rad, norm(pts[3 * k] - cx, pts[3 * k + 1] - cy, pts[3 * k + 2] - cz));
+		rad = (rad + slack) * (1 + 1e-4) + 1e-5 * (1 + mag); // + relative and absolute room for the device-side test's own rounding
+		double r2 = rad * rad;
+		float r2f = (float) r2;
+		if((double) r2f < r2) r2f = std::nextafterf(r2f, INFINITY);
+		if(unbounded || !(r2 == r2)) r2f = INFINITY;
+		tri_chunks[c] = {(float) cx, (float) cy, (float) cz, r2f};
 	}
 }
 

@@ -18,6 +18,8 @@ struct SceneView {
 	const float4 *lights; // LDS [2i] position [2i+1] colour
 	const float4 *tris; // HBM  [3i] v0 [3i+1] e1 [3i+2] e2
 	int ns, nt, nl;
+	const float4 *chunks; // HBM  conservative sphere (centre, radius^2) per 32 triangles, + 1 pad
+	int nchunks;          // 0 = walk every triangle
 };
 
 struct Counters {
@@ -103,9 +105,45 @@ SKR_DEV int closest_sphere(const SceneView &sv, const RayConst &r, float &tmin)
 SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float tmin)
 {
 	bool hit = false;
+	if(sv.nchunks > 0)
+	{ // chunked walk: a line that misses a chunk's conservative sphere cannot pass the test for any of its 32
+	  // triangles (scene_host.cpp build_triangle_chunks), so a chunk that no lane's line touches is skipped whole
+		const float dd = r.two_a * 0.5f; // dot(d, d)
+		float4 c_next = sv.chunks[0];
+		for(int c = 0; c < sv.nchunks; c++)
+		{
+			const float4 ch = c_next;
+			c_next = sv.chunks[c + 1];
+			const f3 e = ld3(ch) - r.o;
+			const f3 cr = cross3(e, r.d);
+			const bool maybe = !hit && !(dot3(cr, cr) > ch.w * dd); // |e x d|^2 <= R^2 |d|^2; NaN => test the chunk
+			if(__any(maybe))
+			{
+				const int i0 = c * 32, i1 = (i0 + 32 < sv.nt) ? i0 + 32 : sv.nt;
+				float4 n0 = sv.tris[3 * i0], n1 = sv.tris[3 * i0 + 1], n2 = sv.tris[3 * i0 + 2];
+				for(int i = i0; i < i1; i++)
+				{
+					const f3 v0 = ld3(n0), e1 = ld3(n1), e2 = ld3(n2);
+					n0 = sv.tris[3 * i + 3];
+					n1 = sv.tris[3 * i + 4];
+					n2 = sv.tris[3 * i + 5];
+					float t;
+					if(maybe && !hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
+				}
+				if(__all(hit)) break;
+			}
+		}
+		return hit;
+	}
+	// wave-uniform addresses => scalar loads; triangle i+1 is fetched while i is tested
+	// (tris[] carries one pad triangle so the prefetch needs no bounds test)
+	float4 n0 = sv.tris[0], n1 = sv.tris[1], n2 = sv.tris[2];
 	for(int i = 0; i < sv.nt; i++)
 	{
-		const f3 v0 = ld3(sv.tris[3 * i]), e1 = ld3(sv.tris[3 * i + 1]), e2 = ld3(sv.tris[3 * i + 2]);
+		const f3 v0 = ld3(n0), e1 = ld3(n1), e2 = ld3(n2);
+		n0 = sv.tris[3 * i + 3];
+		n1 = sv.tris[3 * i + 4];
+		n2 = sv.tris[3 * i + 5];
 		float t;
 		if(!hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
 		if((i & 7) == 7 && __all(hit)) break;
