@@ -93,7 +93,7 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	r->off_tris = 4 * ns + nl2;
 	const size_t nch = scene->tri_chunks.size();
 	r->off_chunks = 4 * ns + nl2 + nt3;
-	r->n_chunks = nch ? (int) nch - 1 : 0; // the last entry is the prefetch pad
+	r->n_chunks = scene->info.n_triangles ? (scene->info.n_triangles + SKR_TRI_CHUNK - 1) / SKR_TRI_CHUNK : 0; // then a pad, the second-level spheres, a pad
 	const size_t total = 4 * ns + nl2 + nt3 + nch;
 	std::vector<skr_f4> blob(total > 0 ? total : 1);
 	if(ns)

@@ -71,10 +71,54 @@ void skr_scene::finalize()
 		lights[2 * i] = {l[0], l[1], l[2], 0.0f};
 		lights[2 * i + 1] = {l[3], l[4], l[5], 0.0f};
 	}
+	// The triangle walk only answers "does any triangle accept this ray before tmin" (raytrace.h:168-176 turns
+	// any such hit black), so the order of tris[] is free: store the triangles along a Morton curve through the
+	// centres of their accept regions, which makes every run of SKR_TRI_CHUNK triangles spatially tight.
+	std::vector<int> order(nt);
+	{
+		std::vector<double> ctr((size_t) nt * 3);
+		double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+		for(int i = 0; i < nt; i++)
+		{
+			const float *t = &raw_triangles[(size_t) i * 9];
+			for(int k = 0; k < 3; k++)
+			{
+				// accept region (v0, v0 - e1, v0 + e2), see build_triangle_chunks()
+				const double c = (double) t[k] + (((double) t[6 + k] - t[k]) - ((double) t[3 + k] - t[k])) / 3.0;
+				ctr[(size_t) i * 3 + k] = c;
+				if(std::isfinite(c)) { lo[k] = std::min(lo[k], c); hi[k] = std::max(hi[k], c); }
+			}
+		}
+		auto spread = [](uint64_t v) { // 21 bits -> every third bit
+			v &= 0x1fffff;
+			v = (v | v << 32) & 0x1f00000000ffffull;
+			v = (v | v << 16) & 0x1f0000ff0000ffull;
+			v = (v | v << 8) & 0x100f00f00f00f00full;
+			v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+			v = (v | v << 2) & 0x1249249249249249ull;
+			return v;
+		};
+		std::vector<uint64_t> key(nt);
+		for(int i = 0; i < nt; i++)
+		{
+			uint64_t code = 0;
+			bool ok = true;
+			for(int k = 0; k < 3; k++)
+			{
+				const double c = ctr[(size_t) i * 3 + k], ext = hi[k] - lo[k];
+				if(!std::isfinite(c)) { ok = false; break; }
+				const double u = ext > 0 ? (c - lo[k]) / ext : 0.0;
+				code |= spread((uint64_t) std::min(2097151.0, std::max(0.0, u * 2097151.0))) << k;
+			}
+			key[i] = ok ? code : ~0ull;
+			order[i] = i;
+		}
+		std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+	}
 	tris.assign((size_t) nt * 3 + 3, skr_f4{0.0f, 0.0f, 0.0f, 0.0f}); // + one pad triangle (kernel prefetch)
 	for(int i = 0; i < nt; i++)
 	{
-		const float *t = &raw_triangles[(size_t) i * 9];
+		const float *t = &raw_triangles[(size_t) order[i] * 9];
 		tris[3 * i] = {t[0], t[1], t[2], 0.0f};
 		tris[3 * i + 1] = {t[3] - t[0], t[4] - t[1], t[5] - t[2], 0.0f};
 		tris[3 * i + 2] = {t[6] - t[0], t[7] - t[1], t[8] - t[2], 0.0f};
@@ -152,6 +196,35 @@ void skr_scene::build_triangle_chunks()
 		if((double) r2f < r2) r2f = std::nextafterf(r2f, INFINITY);
 		if(unbounded || !(r2 == r2)) r2f = INFINITY;
 		tri_chunks[c] = {(float) cx, (float) cy, (float) cz, r2f};
+	}
+	// second level: one sphere around every SKR_TRI_SUPER consecutive chunk spheres (a line that touches a
+	// chunk sphere touches this one), stored behind the chunk entries: [nc + 1 + s]
+	const int nsup = (nc + SKR_TRI_SUPER - 1) / SKR_TRI_SUPER;
+	tri_chunks.resize((size_t) nc + 1 + nsup + 1, skr_f4{0.0f, 0.0f, 0.0f, INFINITY});
+	for(int s = 0; s < nsup; s++)
+	{
+		const int c0 = s * SKR_TRI_SUPER, c1 = std::min(nc, c0 + SKR_TRI_SUPER);
+		double cx = 0, cy = 0, cz = 0, mag = 0;
+		bool unbounded = false;
+		for(int c = c0; c < c1; c++)
+		{
+			cx += tri_chunks[c].x; cy += tri_chunks[c].y; cz += tri_chunks[c].z;
+			if(!(tri_chunks[c].w < INFINITY)) unbounded = true;
+		}
+		cx /= (c1 - c0); cy /= (c1 - c0); cz /= (c1 - c0);
+		double rad = 0;
+		for(int c = c0; c < c1; c++)
+		{
+			const double rc = std::sqrt((double) tri_chunks[c].w) * (1 + 1e-6);
+			rad = std::max(rad, norm(tri_chunks[c].x - cx, tri_chunks[c].y - cy, tri_chunks[c].z - cz) + rc);
+			mag = std::max(mag, std::max(std::fabs((double) tri_chunks[c].x), std::max(std::fabs((double) tri_chunks[c].y), std::fabs((double) tri_chunks[c].z))) + rc);
+		}
+		rad = rad * (1 + 1e-4) + 1e-5 * (1 + mag);
+		const double r2 = rad * rad;
+		float r2f = (float) r2;
+		if((double) r2f < r2) r2f = std::nextafterf(r2f, INFINITY);
+		if(unbounded || !(r2 == r2)) r2f = INFINITY;
+		tri_chunks[(size_t) nc + 1 + s] = {(float) cx, (float) cy, (float) cz, r2f};
 	}
 }
 

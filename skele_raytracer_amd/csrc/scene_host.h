@@ -11,6 +11,7 @@
 #include "../../include/skr.h"
 
 #define SKR_TRI_CHUNK 32
+#define SKR_TRI_SUPER 8 /* chunk spheres per second-level sphere */
 #define SKR_CULL_DMAX 256.0 /* the chunk radii are valid for ray directions up to this length */
 
 struct skr_f4 {

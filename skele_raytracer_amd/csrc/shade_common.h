@@ -109,29 +109,39 @@ SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float t
 	{ // chunked walk: a line that misses a chunk's conservative sphere cannot pass the test for any of its 32
 	  // triangles (scene_host.cpp build_triangle_chunks), so a chunk that no lane's line touches is skipped whole
 		const float dd = r.two_a * 0.5f; // dot(d, d)
-		float4 c_next = sv.chunks[0];
-		for(int c = 0; c < sv.nchunks; c++)
+		const int nsup = (sv.nchunks + 7) >> 3;
+		const float4 *sup = sv.chunks + sv.nchunks + 1; // second-level spheres, one per 8 chunks
+		for(int s = 0; s < nsup; s++)
 		{
-			const float4 ch = c_next;
-			c_next = sv.chunks[c + 1];
-			const f3 e = ld3(ch) - r.o;
-			const f3 cr = cross3(e, r.d);
-			const bool maybe = !hit && !(dot3(cr, cr) > ch.w * dd); // |e x d|^2 <= R^2 |d|^2; NaN => test the chunk
-			if(__any(maybe))
+			const float4 sp = sup[s];
+			const f3 es = ld3(sp) - r.o;
+			const f3 crs = cross3(es, r.d);
+			if(!__any(!hit && !(dot3(crs, crs) > sp.w * dd))) continue; // no lane's line touches any of its 8 chunk spheres
+			const int c0 = s << 3, c1 = (c0 + 8 < sv.nchunks) ? c0 + 8 : sv.nchunks;
+			float4 c_next = sv.chunks[c0];
+			for(int c = c0; c < c1; c++)
 			{
-				const int i0 = c * 32, i1 = (i0 + 32 < sv.nt) ? i0 + 32 : sv.nt;
-				float4 n0 = sv.tris[3 * i0], n1 = sv.tris[3 * i0 + 1], n2 = sv.tris[3 * i0 + 2];
-				for(int i = i0; i < i1; i++)
+				const float4 ch = c_next;
+				c_next = sv.chunks[c + 1];
+				const f3 e = ld3(ch) - r.o;
+				const f3 cr = cross3(e, r.d);
+				const bool maybe = !hit && !(dot3(cr, cr) > ch.w * dd); // |e x d|^2 <= R^2 |d|^2; NaN => test the chunk
+				if(__any(maybe))
 				{
-					const f3 v0 = ld3(n0), e1 = ld3(n1), e2 = ld3(n2);
-					n0 = sv.tris[3 * i + 3];
-					n1 = sv.tris[3 * i + 4];
-					n2 = sv.tris[3 * i + 5];
-					float t;
-					if(maybe && !hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
+					const int i0 = c * 32, i1 = (i0 + 32 < sv.nt) ? i0 + 32 : sv.nt;
+					float4 n0 = sv.tris[3 * i0], n1 = sv.tris[3 * i0 + 1], n2 = sv.tris[3 * i0 + 2];
+					for(int i = i0; i < i1; i++)
+					{
+						const f3 v0 = ld3(n0), e1 = ld3(n1), e2 = ld3(n2);
+						n0 = sv.tris[3 * i + 3];
+						n1 = sv.tris[3 * i + 4];
+						n2 = sv.tris[3 * i + 5];
+						float t;
+						if(maybe && !hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
+					}
 				}
-				if(__all(hit)) break;
 			}
+			if(__all(hit)) break;
 		}
 		return hit;
 	}

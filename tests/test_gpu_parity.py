@@ -282,3 +282,20 @@ def test_all_kernel_variants_agree(gpu, monkeypatch):
     assert seen == {"parent_queue_v3", "wave_streaming_v2", "lane_per_pixel_dfs_v1f"}
     for k in ("SKR_PIPELINE", "SKR_KERNEL", "SKR_OCC", "SKR_TILE"):
         monkeypatch.delenv(k, raising=False)
+
+
+@pytest.mark.parametrize("scn,w,h,kw", [("dragon.scn", 1920, 1080, dict(gillum=16)), ("test.scn", 320, 180, dict(gillum=4, shadow=True, seed=2)),
+                                        ("dragon.scn", 333, 187, dict(fov=120.0, jsample=2, seed=4))], ids=["dragon_1080p", "test_gi", "dragon_fov120_aa"])
+def test_triangle_chunk_culling_changes_nothing(gpu, monkeypatch, scn, w, h, kw):
+    """The chunk spheres (scene_host.cpp build_triangle_chunks) may only skip triangles that would have failed
+    utils.h:181-213 anyway: the culled walk must reproduce the brute-force walk bit for bit (BASELINE config 4 at full size)."""
+    r = renderer(scn)
+    opt = skr.Options(w, h, **kw)
+    monkeypatch.delenv("SKR_NO_CULL", raising=False)
+    a, af = r.render(opt, want_float=True)
+    monkeypatch.setenv("SKR_NO_CULL", "1")
+    b, bf = r.render(opt, want_float=True)
+    monkeypatch.delenv("SKR_NO_CULL", raising=False)
+    gpu.cuda.synchronize()
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+    assert np.array_equal(af.cpu().numpy().view(np.uint32), bf.cpu().numpy().view(np.uint32))
