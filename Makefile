@@ -12,7 +12,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-
             -fno-fast-math -Wall -Wno-unused-function -Iinclude
 KERNEL_SRCS := $(CSRC)/render_kernel.hip $(CSRC)/render_wave.hip
 HOST_SRCS   := $(CSRC)/api.cpp $(CSRC)/scene_host.cpp
-HDRS        := include/skr.h $(CSRC)/device_math.h $(CSRC)/shade_common.h $(CSRC)/render_params.h $(CSRC)/scene_host.h
+HDRS        := include/skr.h $(CSRC)/device_math.h $(CSRC)/shade_common.h $(CSRC)/render_params.h $(CSRC)/scene_host.h $(CSRC)/tri_chunks.h
 
 all: lib cli oracle
 

@@ -36,7 +36,8 @@ class CSceneInfo(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libskr.so")
+    """lib/libskr.so, or the build named by SKR_LIBRARY (kernel experiments: same ABI, other tuning macros)."""
+    return os.environ.get("SKR_LIBRARY") or os.path.join(_HERE, "lib", "libskr.so")
 
 
 _lib = None

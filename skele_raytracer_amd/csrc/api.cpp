@@ -36,7 +36,7 @@ struct skr_renderer {
 	skr_scene_info info{};
 	float4 *d_blob = nullptr; // one allocation: geom | amb | kd | ks | lights | tris
 	size_t off_amb = 0, off_kd = 0, off_ks = 0, off_lights = 0, off_tris = 0, off_chunks = 0;
-	int n_chunks = 0;
+	int n_chunks = 0, chunk_size = 0;
 	unsigned long long *d_counters = nullptr;
 	int lds_limit = 0;
 	// scratch of the parent-queue pipeline, grown on demand and kept
@@ -93,7 +93,8 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	r->off_tris = 4 * ns + nl2;
 	const size_t nch = scene->tri_chunks.size();
 	r->off_chunks = 4 * ns + nl2 + nt3;
-	r->n_chunks = scene->info.n_triangles ? (scene->info.n_triangles + SKR_TRI_CHUNK - 1) / SKR_TRI_CHUNK : 0; // then a pad, the second-level spheres, a pad
+	r->chunk_size = scene->tri_chunk_size;
+	r->n_chunks = scene->info.n_triangles ? (scene->info.n_triangles + r->chunk_size - 1) / r->chunk_size : 0; // then a pad, the second-level spheres, a pad
 	const size_t total = 4 * ns + nl2 + nt3 + nch;
 	std::vector<skr_f4> blob(total > 0 ? total : 1);
 	if(ns)
@@ -221,6 +222,7 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.lights = r->d_blob + r->off_lights;
 	p.tris = r->d_blob + r->off_tris;
 	p.tri_chunks = r->d_blob + r->off_chunks;
+	p.tri_chunk_size = r->chunk_size;
 	{ // the chunk spheres are valid for |d| <= SKR_CULL_DMAX: primary directions are dir + u right + v up, GI ones stay below 4
 		auto len3 = [](const float *v) { return std::sqrt((double) v[0] * v[0] + (double) v[1] * v[1] + (double) v[2] * v[2]); };
 		const double umax = std::fabs((double) p.angle * p.aspect) * 1.001, vmax = std::fabs((double) p.angle) * 1.001;

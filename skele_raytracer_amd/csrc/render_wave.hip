@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 	using C = Cfg<OCC>;
 	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * C::WAVE_LDS_FLOATS;
 	Wave w;
-	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks};
+	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size};
 	w.p = &p;
 	w.slots = wbase;
 	w.lane = lane;
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(256) void skr_primary_kernel(const RenderParams p)
 	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
 	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	__syncthreads();
-	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks};
+	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size};
 
 	const int wave = tid >> 6, lane = tid & 63;
 	const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 	using C = Cfg<OCC, true>;
 	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * C::WAVE_LDS_FLOATS;
 	Wave w;
-	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks};
+	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size};
 	w.p = &p;
 	w.slots = wbase;
 	w.lane = lane;
@@ -1257,6 +1257,7 @@ bool skr_queue_selected(const RenderParams &p)
 {
 	const char *e = getenv("SKR_PIPELINE");
 	if(e && !strcmp(e, "mega")) return false;
+	if(e && !strcmp(e, "queue")) return skr_wave_supported(p) && p.monte_carlo && p.max_depth >= 2 && p.num_path_traces > 0;
 	return skr_wave_supported(p) && p.monte_carlo && p.n_spheres > 0 && p.max_depth >= 2 && p.num_path_traces > 0;
 }
 

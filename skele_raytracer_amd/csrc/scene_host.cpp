@@ -73,7 +73,7 @@ void skr_scene::finalize()
 	}
 	// The triangle walk only answers "does any triangle accept this ray before tmin" (raytrace.h:168-176 turns
 	// any such hit black), so the order of tris[] is free: store the triangles along a Morton curve through the
-	// centres of their accept regions, which makes every run of SKR_TRI_CHUNK triangles spatially tight.
+	// centres of their accept regions, which makes every run of tri_chunk_size triangles spatially tight.
 	std::vector<int> order(nt);
 	{
 		std::vector<double> ctr((size_t) nt * 3);
@@ -155,11 +155,12 @@ void skr_scene::build_triangle_chunks()
 		const float *s = &raw_spheres[(size_t) i * 14];
 		orgs.push_back({s[0], s[1], s[2], std::fabs((double) s[3]) + 1e-3});
 	}
-	const int nc = (nt + SKR_TRI_CHUNK - 1) / SKR_TRI_CHUNK;
+	tri_chunk_size = info.n_spheres == 0 ? SKR_TRI_CHUNK_COHERENT : SKR_TRI_CHUNK_MIXED; // see tri_chunks.h
+	const int nc = (nt + tri_chunk_size - 1) / tri_chunk_size;
 	tri_chunks.assign((size_t) nc + 1, skr_f4{0.0f, 0.0f, 0.0f, INFINITY}); // + pad entry
 	for(int c = 0; c < nc; c++)
 	{
-		const int i0 = c * SKR_TRI_CHUNK, i1 = std::min(nt, i0 + SKR_TRI_CHUNK);
+		const int i0 = c * tri_chunk_size, i1 = std::min(nt, i0 + tri_chunk_size);
 		double cx = 0, cy = 0, cz = 0;
 		int np = 0;
 		std::vector<double> pts;

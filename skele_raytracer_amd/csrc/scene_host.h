@@ -9,10 +9,8 @@
 #include <vector>
 
 #include "../../include/skr.h"
+#include "tri_chunks.h"
 
-#define SKR_TRI_CHUNK 32
-#define SKR_TRI_SUPER 8 /* chunk spheres per second-level sphere */
-#define SKR_CULL_DMAX 256.0 /* the chunk radii are valid for ray directions up to this length */
 
 struct skr_f4 {
 	float x, y, z, w;
@@ -32,9 +30,10 @@ struct skr_scene {
 	std::vector<skr_f4> sph_ks;   // material.specular
 	std::vector<skr_f4> lights;   // [2*i] position, [2*i+1] colour
 	std::vector<skr_f4> tris;     // [3*i] v0, [3*i+1] v1-v0, [3*i+2] v2-v0 (utils.h:183-184 subtractions)
-	// one conservative bounding sphere (centre, radius^2) per SKR_TRI_CHUNK consecutive triangles: a line that
+	// one conservative bounding sphere (centre, radius^2) per tri_chunk_size consecutive triangles: a line that
 	// misses it cannot pass utils.h:181-213 for any triangle of the chunk (see finalize())
 	std::vector<skr_f4> tri_chunks;
+	int tri_chunk_size = SKR_TRI_CHUNK_MIXED;
 
 	void finalize();
 	void build_triangle_chunks();

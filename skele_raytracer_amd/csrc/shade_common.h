@@ -4,6 +4,7 @@
 
 #include "device_math.h"
 #include "render_params.h"
+#include "tri_chunks.h"
 
 namespace {
 
@@ -20,6 +21,7 @@ struct SceneView {
 	int ns, nt, nl;
 	const float4 *chunks; // HBM  conservative sphere (centre, radius^2) per 32 triangles, + 1 pad
 	int nchunks;          // 0 = walk every triangle
+	int chunk;            // triangles per chunk sphere (tri_chunks.h)
 };
 
 struct Counters {
@@ -109,15 +111,17 @@ SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float t
 	{ // chunked walk: a line that misses a chunk's conservative sphere cannot pass the test for any of its 32
 	  // triangles (scene_host.cpp build_triangle_chunks), so a chunk that no lane's line touches is skipped whole
 		const float dd = r.two_a * 0.5f; // dot(d, d)
-		const int nsup = (sv.nchunks + 7) >> 3;
-		const float4 *sup = sv.chunks + sv.nchunks + 1; // second-level spheres, one per 8 chunks
+		const int nsup = (sv.nchunks + SKR_TRI_SUPER - 1) / SKR_TRI_SUPER;
+		const float4 *sup = sv.chunks + sv.nchunks + 1; // second-level spheres
+		float4 sp_next = sup[0];
 		for(int s = 0; s < nsup; s++)
 		{
-			const float4 sp = sup[s];
+			const float4 sp = sp_next;
+			sp_next = sup[s + 1]; // padded
 			const f3 es = ld3(sp) - r.o;
 			const f3 crs = cross3(es, r.d);
-			if(!__any(!hit && !(dot3(crs, crs) > sp.w * dd))) continue; // no lane's line touches any of its 8 chunk spheres
-			const int c0 = s << 3, c1 = (c0 + 8 < sv.nchunks) ? c0 + 8 : sv.nchunks;
+			if(!__any(!hit && !(dot3(crs, crs) > sp.w * dd))) continue; // no lane's line touches any of its chunk spheres
+			const int c0 = s * SKR_TRI_SUPER, c1 = (c0 + SKR_TRI_SUPER < sv.nchunks) ? c0 + SKR_TRI_SUPER : sv.nchunks;
 			float4 c_next = sv.chunks[c0];
 			for(int c = c0; c < c1; c++)
 			{
@@ -128,7 +132,7 @@ SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float t
 				const bool maybe = !hit && !(dot3(cr, cr) > ch.w * dd); // |e x d|^2 <= R^2 |d|^2; NaN => test the chunk
 				if(__any(maybe))
 				{
-					const int i0 = c * 32, i1 = (i0 + 32 < sv.nt) ? i0 + 32 : sv.nt;
+					const int i0 = c * sv.chunk, i1 = (i0 + sv.chunk < sv.nt) ? i0 + sv.chunk : sv.nt;
 					float4 n0 = sv.tris[3 * i0], n1 = sv.tris[3 * i0 + 1], n2 = sv.tris[3 * i0 + 2];
 					for(int i = i0; i < i1; i++)
 					{
