@@ -299,3 +299,43 @@ def test_triangle_chunk_culling_changes_nothing(gpu, monkeypatch, scn, w, h, kw)
     gpu.cuda.synchronize()
     assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
     assert np.array_equal(af.cpu().numpy().view(np.uint32), bf.cpu().numpy().view(np.uint32))
+
+
+def _write_triangle_soup(path, rng, n_tris, with_spheres):
+    """Many small triangles of very different sizes (edge 1e-3 .. 2, slivers included) in front of the camera:
+    the culling spheres of scene_host.cpp must never hide one from a ray the brute-force oracle lets it stop."""
+    lines = ["camera 0 1.5 -9 0 -.05 1 0 1 0 30", "background .2 .3 .4", "ambient_light .3 .3 .3"]
+    if with_spheres:
+        lines += ["material .6 .6 .6 .7 .7 .7 .2 .2 .2 8 0 0 0 1", "sphere 0 -40 0 40",
+                  "material .2 .5 .6 .3 .7 .7 .4 .4 .4 16 0 0 0 1", "sphere -2 1 1 1", "sphere 2.5 1.2 3 1.2",
+                  "point_light 30 30 30 6 8 -6"]
+    for _ in range(n_tris):
+        c = np.array([rng.uniform(-6, 6), rng.uniform(-1, 6), rng.uniform(-2, 12)])
+        size = 10.0 ** rng.uniform(-3, 0.3)
+        a, b = rng.normal(size=3) * size, rng.normal(size=3) * size
+        if rng.random() < 0.2:
+            b = a * rng.uniform(0.5, 2) + rng.normal(size=3) * size * 1e-3  # sliver: |det| near the 1e-5 cut
+        for v in (c, c + a, c + b):
+            lines.append("vertex %.9g %.9g %.9g" % tuple(v))
+    for i in range(n_tris):
+        lines.append("triangle %d %d %d" % (3 * i, 3 * i + 1, 3 * i + 2))
+    open(path, "w").write("\n".join(lines) + "\n")
+
+
+@pytest.mark.parametrize("n_tris,with_spheres,kw", [
+    (700, True, dict(gillum=4, depth=2, shadow=True, seed=11)),   # GI children start on spheres, incoherent waves
+    (1500, False, dict(jsample=2, seed=12)),                     # sphere-free: 8-triangle chunks, jittered camera rays
+    (333, True, dict(fov=150.0, seed=13)),                       # long un-normalised primary directions (|d| ~ 7)
+], ids=["soup700_gi", "soup1500_aa", "soup333_fov150"])
+def test_triangle_soup_matches_oracle(gpu, oracle, tmp_path, n_tris, with_spheres, kw):
+    rng = np.random.default_rng(n_tris)
+    scn = str(tmp_path / "soup.scn")
+    _write_triangle_soup(scn, rng, n_tris, with_spheres)
+    w, h = 128, 72
+    r = skr.Renderer(skr.parse_scene(scn))
+    rgb, rgbf = r.render(skr.Options(w, h, **kw), want_float=True)
+    gpu.cuda.synchronize()
+    o_rgb, o_f, st = oracle.render(scn, w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, **kw)
+    compare(rgb.cpu().numpy(), rgbf.cpu().numpy(), o_rgb, o_f, "soup %d" % n_tris)
+    black = int((o_rgb.reshape(-1, 3).sum(axis=1) == 0).sum())
+    assert black > 10, "the soup must actually cover pixels (%d black)" % black
