@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # every symbol include/skr.h declares (tests/test_abi.py checks the library exports them)
 EXPORTED_SYMBOLS = [
     "skr_scene_create_from_scn", "skr_scene_create_from_arrays", "skr_scene_destroy", "skr_scene_get_info",
-    "skr_scene_get_arrays", "skr_options_default", "skr_radiance_ray_count", "skr_device_count",
+    "skr_scene_get_arrays", "skr_scene_get_culling", "skr_options_default", "skr_radiance_ray_count", "skr_device_count",
     "skr_renderer_create", "skr_renderer_destroy", "skr_render_tiles", "skr_tile_count", "skr_render_rows",
     "skr_renderer_read_counters", "skr_renderer_kernel_timing", "skr_renderer_kernel_ms", "skr_renderer_last_parent_count", "skr_render_frame_host", "skr_write_ppm", "skr_last_error",
     "skr_kernel_variant", "skr_debug_eval",
@@ -64,6 +64,7 @@ def lib():
     L.skr_scene_destroy.restype = None
     L.skr_scene_get_info.argtypes = [vp, C.POINTER(CSceneInfo)]
     L.skr_scene_get_arrays.argtypes = [vp, vp, vp, vp]
+    L.skr_scene_get_culling.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp, vp, vp]
     L.skr_options_default.argtypes = [C.POINTER(COptions)]
     L.skr_options_default.restype = None
     L.skr_radiance_ray_count.argtypes = [C.POINTER(COptions)]
@@ -146,6 +147,16 @@ class Scene:
         l = np.zeros((i.n_point_lights, 6), np.float32)
         _check(lib().skr_scene_get_arrays(self.h, s.ctypes.data, t.ctypes.data, l.ctypes.data), "skr_scene_get_arrays")
         return s, t, l
+
+    def culling(self, level=0):
+        """(chunk_size, device_tris [n,3,4], chunk_spheres [nc,4], super_spheres [ns,4]) — include/skr.h skr_scene_get_culling."""
+        cs, nc, ns = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(lib().skr_scene_get_culling(self.h, level, C.byref(cs), C.byref(nc), C.byref(ns), None, None, None), "skr_scene_get_culling")
+        tris = np.zeros((self.info.n_triangles, 3, 4), np.float32)
+        ch = np.zeros((nc.value, 4), np.float32)
+        sup = np.zeros((ns.value, 4), np.float32)
+        _check(lib().skr_scene_get_culling(self.h, level, None, None, None, tris.ctypes.data, ch.ctypes.data, sup.ctypes.data), "skr_scene_get_culling")
+        return cs.value, tris, ch, sup
 
     @staticmethod
     def from_arrays(spheres, triangles, point_lights, camera, background=(0, 0, 0), ambient=(0, 0, 0)):

@@ -37,6 +37,7 @@ struct skr_renderer {
 	float4 *d_blob = nullptr; // one allocation: geom | amb | kd | ks | lights | tris
 	size_t off_amb = 0, off_kd = 0, off_ks = 0, off_lights = 0, off_tris = 0, off_chunks = 0;
 	int n_chunks = 0, chunk_size = 0;
+	size_t chunk_stride = 0;
 	unsigned long long *d_counters = nullptr;
 	int lds_limit = 0;
 	// scratch of the parent-queue pipeline, grown on demand and kept
@@ -94,6 +95,7 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	const size_t nch = scene->tri_chunks.size();
 	r->off_chunks = 4 * ns + nl2 + nt3;
 	r->chunk_size = scene->tri_chunk_size;
+	r->chunk_stride = scene->tri_chunk_stride;
 	r->n_chunks = scene->info.n_triangles ? (scene->info.n_triangles + r->chunk_size - 1) / r->chunk_size : 0; // then a pad, the second-level spheres, a pad
 	const size_t total = 4 * ns + nl2 + nt3 + nch;
 	std::vector<skr_f4> blob(total > 0 ? total : 1);
@@ -223,11 +225,16 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.tris = r->d_blob + r->off_tris;
 	p.tri_chunks = r->d_blob + r->off_chunks;
 	p.tri_chunk_size = r->chunk_size;
-	{ // the chunk spheres are valid for |d| <= SKR_CULL_DMAX: primary directions are dir + u right + v up, GI ones stay below 4
+	{ // pick the tightest set of chunk spheres whose |d| bound covers this frame's camera rays (GI children stay below 4,
+	  // the smallest bound): primary directions are dir + u right + v up (main.cpp:154-155)
 		auto len3 = [](const float *v) { return std::sqrt((double) v[0] * v[0] + (double) v[1] * v[1] + (double) v[2] * v[2]); };
 		const double umax = std::fabs((double) p.angle * p.aspect) * 1.001, vmax = std::fabs((double) p.angle) * 1.001;
 		const double dmax = len3(c + 3) + umax * len3(c + 9) + vmax * len3(c + 6);
-		p.n_tri_chunks = (dmax < SKR_CULL_DMAX && !getenv("SKR_NO_CULL")) ? r->n_chunks : 0;
+		const double bound[SKR_CULL_LEVELS] = SKR_CULL_DMAX_LIST;
+		int level = 0;
+		while(level < SKR_CULL_LEVELS && !(dmax < bound[level])) level++;
+		p.n_tri_chunks = (level < SKR_CULL_LEVELS && !getenv("SKR_NO_CULL")) ? r->n_chunks : 0;
+		if(p.n_tri_chunks) p.tri_chunks += (size_t) level * r->chunk_stride;
 	}
 	p.monte_carlo = opt->monte_carlo ? 1 : 0;
 	p.num_path_traces = opt->num_path_traces;

@@ -136,14 +136,26 @@ void skr_scene::finalize()
 // (eps = 2^-24; three-term dot products and 2x2 cross terms of rounded inputs, divided by a determinant that
 // the test itself bounds away from zero), so an accepted line passes within eta_u |e1| + eta_v |e2| of that
 // triangle.  Every chunk gets a sphere around its triangles' accept regions, inflated by 16x that slack
-// (evaluated for |d| <= SKR_CULL_DMAX and the farthest possible ray origin: camera or any sphere surface) plus
+// (evaluated for |d| <= d_max, one set of spheres per entry of SKR_CULL_DMAX_LIST, and the farthest possible ray origin: camera or any sphere surface) plus
 // an absolute term for the rounding of the device's own line-sphere test.  Where the slack is not small the
 // radius becomes infinite and the chunk is simply never culled.
 void skr_scene::build_triangle_chunks()
 {
-	const int nt = info.n_triangles;
 	tri_chunks.clear();
-	if(nt == 0) return;
+	if(info.n_triangles == 0) return;
+	const double dmax[SKR_CULL_LEVELS] = SKR_CULL_DMAX_LIST;
+	for(int level = 0; level < SKR_CULL_LEVELS; level++)
+	{
+		std::vector<skr_f4> one;
+		build_triangle_chunk_level(dmax[level], one);
+		tri_chunk_stride = one.size();
+		tri_chunks.insert(tri_chunks.end(), one.begin(), one.end());
+	}
+}
+
+void skr_scene::build_triangle_chunk_level(double d_max, std::vector<skr_f4> &tri_chunks)
+{
+	const int nt = info.n_triangles;
 	const double eps = 5.9604644775390625e-08; // 2^-24
 	auto norm = [](double x, double y, double z) { return std::sqrt(x * x + y * y + z * z); };
 	// where rays can start: the camera, or on a sphere (GI children, raytrace.h:128)
@@ -181,9 +193,9 @@ void skr_scene::build_triangle_chunks()
 			double tmax = 0;
 			for(const Org &o : orgs) tmax = std::max(tmax, norm(o.x - v0.x, o.y - v0.y, o.z - v0.z) + o.r);
 			const double l1 = norm(e1.x, e1.y, e1.z), l2 = norm(e2.x, e2.y, e2.z);
-			const double eta_u = 7 * eps * SKR_CULL_DMAX * l2 * (tmax + 1.01 * l1) / 0.99e-5;
-			const double eta_v = 7 * eps * SKR_CULL_DMAX * l1 * (tmax + 1.01 * l2) / 0.99e-5;
-			const double rho_det = 7 * eps * SKR_CULL_DMAX * l1 * l2 / 1e-5; // relative error of the computed determinant at the 1e-5 threshold
+			const double eta_u = 7 * eps * d_max * l2 * (tmax + 1.01 * l1) / 0.99e-5;
+			const double eta_v = 7 * eps * d_max * l1 * (tmax + 1.01 * l2) / 0.99e-5;
+			const double rho_det = 7 * eps * d_max * l1 * l2 / 1e-5; // relative error of the computed determinant at the 1e-5 threshold
 			if(!(eta_u < 0.25) || !(eta_v < 0.25) || !(rho_det < 0.01)) unbounded = true;
 			slack = std::max(slack, 16 * (eta_u * l1 + eta_v * l2));
 			mag = std::max(mag, tmax);
@@ -465,6 +477,22 @@ int skr_scene_get_arrays(const skr_scene *scene, float *spheres, float *triangle
 	if(spheres && !scene->raw_spheres.empty()) memcpy(spheres, scene->raw_spheres.data(), scene->raw_spheres.size() * 4);
 	if(triangles && !scene->raw_triangles.empty()) memcpy(triangles, scene->raw_triangles.data(), scene->raw_triangles.size() * 4);
 	if(point_lights && !scene->raw_point_lights.empty()) memcpy(point_lights, scene->raw_point_lights.data(), scene->raw_point_lights.size() * 4);
+	return SKR_OK;
+}
+
+int skr_scene_get_culling(const skr_scene *scene, int32_t level, int32_t *chunk_size, int32_t *n_chunks, int32_t *n_super,
+						  float *device_tris, float *chunk_spheres, float *super_spheres)
+{
+	if(!scene || level < 0 || level >= SKR_CULL_LEVELS) return SKR_ERR_ARG;
+	const skr_f4 *base = scene->tri_chunks.data() + (size_t) level * scene->tri_chunk_stride;
+	const int nt = scene->info.n_triangles, cs = scene->tri_chunk_size;
+	const int nc = nt ? (nt + cs - 1) / cs : 0, nsup = (nc + SKR_TRI_SUPER - 1) / SKR_TRI_SUPER;
+	if(chunk_size) *chunk_size = cs;
+	if(n_chunks) *n_chunks = nc;
+	if(n_super) *n_super = nsup;
+	if(device_tris && nt) memcpy(device_tris, scene->tris.data(), (size_t) nt * 48);
+	if(chunk_spheres && nc) memcpy(chunk_spheres, base, (size_t) nc * 16);
+	if(super_spheres && nsup) memcpy(super_spheres, base + nc + 1, (size_t) nsup * 16);
 	return SKR_OK;
 }
 

@@ -32,11 +32,13 @@ struct skr_scene {
 	std::vector<skr_f4> tris;     // [3*i] v0, [3*i+1] v1-v0, [3*i+2] v2-v0 (utils.h:183-184 subtractions)
 	// one conservative bounding sphere (centre, radius^2) per tri_chunk_size consecutive triangles: a line that
 	// misses it cannot pass utils.h:181-213 for any triangle of the chunk (see finalize())
-	std::vector<skr_f4> tri_chunks;
+	std::vector<skr_f4> tri_chunks; // SKR_CULL_LEVELS sets of them, one per bound on |d| (tri_chunks.h)
 	int tri_chunk_size = SKR_TRI_CHUNK_MIXED;
 
 	void finalize();
+	size_t tri_chunk_stride = 0; // entries per level: chunks, pad, second-level spheres, pad
 	void build_triangle_chunks();
+	void build_triangle_chunk_level(double d_max, std::vector<skr_f4> &out);
 };
 
 // scene.cpp:12-227 replacement.  Returns SKR_OK or SKR_ERR_IO.

@@ -11,4 +11,10 @@
 #ifndef SKR_TRI_SUPER
 #define SKR_TRI_SUPER 8 /* first-level spheres per second-level sphere */
 #endif
-#define SKR_CULL_DMAX 256.0 /* the sphere radii are valid for ray directions up to this length */
+/* The rounding slack of the triangle test grows with |d| (its |det| >= 1e-5 cut is absolute), so the spheres are
+ * built for three bounds on the direction length and the launcher picks the tightest one that covers the frame:
+ * GI children are at most 3 long (raytrace.h:123-125 mixes three unit vectors with a unit sample), camera rays
+ * |direction + u right + v up| depend on the .scn camera and --fov (main.cpp:154-155). */
+#define SKR_CULL_LEVELS 3
+#define SKR_CULL_DMAX_LIST {4.0, 32.0, 256.0}
+#define SKR_CULL_DMAX 256.0 /* beyond the last bound the walk is brute force */

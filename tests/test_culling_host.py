@@ -1,0 +1,176 @@
+"""Host logic of the triangle culling hierarchy (csrc/scene_host.cpp build_triangle_chunks) — no GPU.
+
+The device walk skips a chunk of triangles when `|e x d|^2 > R^2 |d|^2` for its sphere.  These tests restate both
+sides in numpy binary32 with the device's operation order — the acceptance test of utils.h:181-213
+(device_math.h triangle_hit) and the sphere test of shade_common.h any_triangle_closer — and check, on rays aimed
+at the borders of the accept regions, that no accepted (ray, triangle) pair is ever hidden by its spheres.
+"""
+import numpy as np
+import pytest
+
+import skele_raytracer_amd as skr
+from conftest import scene_path
+
+f32 = np.float32
+
+
+def _dot(a, b):
+    return (a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) + a[..., 2] * b[..., 2]
+
+
+def _cross(x, y):  # glm operand order, as device_math.h cross3
+    return np.stack([x[..., 1] * y[..., 2] - y[..., 1] * x[..., 2],
+                     x[..., 2] * y[..., 0] - y[..., 2] * x[..., 0],
+                     x[..., 0] * y[..., 1] - y[..., 0] * x[..., 1]], axis=-1)
+
+
+def triangle_accepts(o, d, v0, e1, e2):
+    """utils.h:181-213 in binary32, vectorised (all arrays float32, shape [n,3])."""
+    with np.errstate(all="ignore"):
+        p = _cross(d, e2)
+        det = _dot(e1, p)
+        ok = ~(np.abs(det) < f32(0.00001))
+        inv = f32(1.0) / det
+        tv = o - v0
+        u = inv * _dot(-tv, p)
+        ok &= ~((u < 0) | (u > 1))
+        q = _cross(tv, e1)
+        v = _dot(d, q) * inv
+        ok &= ~((v < 0) | (u + v > 1))
+    return ok
+
+
+def sphere_culls(o, d, sph):
+    """shade_common.h: skip iff dot(cr,cr) > R^2 * dot(d,d), cr = cross(centre - o, d); NaN never culls."""
+    with np.errstate(all="ignore"):
+        e = sph[..., :3] - o
+        cr = _cross(e, d)
+        return _dot(cr, cr) > sph[..., 3] * _dot(d, d)
+
+
+def _scene(name):
+    return skr.parse_scene(scene_path(name))
+
+
+@pytest.mark.parametrize("name", ["dragon.scn", "test.scn", "spheres1.scn"])
+def test_device_triangles_are_a_permutation_of_the_file_triangles(name):
+    sc = _scene(name)
+    _, raw, _ = sc.arrays()
+    cs, tris, ch, sup = sc.culling()
+    n = raw.shape[0]
+    want = np.concatenate([raw[:, 0:3], raw[:, 3:6] - raw[:, 0:3], raw[:, 6:9] - raw[:, 0:3]], axis=1)  # utils.h:183-184
+    got = tris[:, :, :3].reshape(n, 9)
+    assert np.all(tris[:, :, 3] == 0)
+    key = lambda a: a[np.lexsort(a.T[::-1])]
+    assert np.array_equal(key(want), key(got))
+    assert cs == (8 if sc.info.n_spheres == 0 else 32)
+    assert ch.shape[0] == (n + cs - 1) // cs and sup.shape[0] == (ch.shape[0] + 7) // 8
+
+
+@pytest.mark.parametrize("name", ["dragon.scn", "test.scn", "spheres1.scn"])
+def test_spheres_contain_their_accept_regions_and_children(name):
+    sc = _scene(name)
+    cs, tris, ch, sup = sc.culling()
+    t = tris.astype(np.float64)
+    v0, e1, e2 = t[:, 0, :3], t[:, 1, :3], t[:, 2, :3]
+    corners = np.stack([v0, v0 - e1, v0 + e2], axis=1)  # the mirrored triangle the reference's test accepts
+    chunk_of = np.arange(t.shape[0]) // cs
+    c = ch[chunk_of].astype(np.float64)
+    dist = np.linalg.norm(corners - c[:, None, :3], axis=2).max(axis=1)
+    finite = np.isfinite(c[:, 3])
+    assert np.all(dist[finite] < np.sqrt(c[finite, 3])), "an accept region sticks out of its chunk sphere"
+    s = sup[np.arange(ch.shape[0]) // 8].astype(np.float64)
+    both = np.isfinite(s[:, 3])
+    assert np.all(np.isfinite(ch[both, 3])), "an unbounded chunk under a bounded second-level sphere"
+    reach = np.linalg.norm(ch[both, :3].astype(np.float64) - s[both, :3], axis=1) + np.sqrt(ch[both, 3].astype(np.float64))
+    assert np.all(reach < np.sqrt(s[both, 3]))
+    # the Morton order must have made the chunks small: median chunk radius well below the mesh extent
+    extent = np.linalg.norm(v0.max(axis=0) - v0.min(axis=0))
+    if name == "dragon.scn":
+        assert np.median(np.sqrt(ch[np.isfinite(ch[:, 3]), 3])) < 0.12 * extent
+
+
+BOUNDS = (4.0, 32.0, 256.0)  # csrc/tri_chunks.h SKR_CULL_DMAX_LIST
+
+
+def _border_rays(rng, sc, tris, n, level):
+    """Rays from the places rays can start (camera; points on spheres) through points on or next to the border
+    of randomly chosen triangles' accept regions — where rounding decides acceptance.  Camera rays are as long
+    as the level's bound allows, rays from spheres (GI children) at most 3 (raytrace.h:123-125)."""
+    i = sc.info
+    cam = np.array(list(i.camera)[:3], np.float64)
+    sph, _, _ = sc.arrays()
+    nt = tris.shape[0]
+    k = rng.integers(0, nt, n)
+    t = tris[k].astype(np.float64)
+    v0, e1, e2 = t[:, 0, :3], t[:, 1, :3], t[:, 2, :3]
+    a = rng.random(n)
+    edge = rng.integers(0, 3, n)
+    A, B, Cc = v0, v0 - e1, v0 + e2
+    P = np.where((edge == 0)[:, None], A + a[:, None] * (B - A), np.where((edge == 1)[:, None], B + a[:, None] * (Cc - B), Cc + a[:, None] * (A - Cc)))
+    centroid = (A + B + Cc) / 3
+    # from far inside to slightly outside the border, on a log scale of relative offsets
+    off = (10.0 ** rng.uniform(-8, -0.3, n)) * rng.choice([-1.0, 1.0], n)
+    P = P + off[:, None] * (centroid - P)
+    o = np.repeat(cam[None], n, axis=0)
+    from_cam = np.ones(n, bool)
+    if sph.shape[0]:
+        j = rng.integers(0, sph.shape[0], n)
+        dirn = rng.normal(size=(n, 3))
+        dirn /= np.linalg.norm(dirn, axis=1, keepdims=True)
+        on_sphere = sph[j, :3].astype(np.float64) + dirn * np.abs(sph[j, 3:4].astype(np.float64))
+        from_cam = rng.random(n) < 0.5
+        o = np.where(from_cam[:, None], o, on_sphere)
+    d = P - o
+    ln = np.linalg.norm(d, axis=1, keepdims=True)
+    longest = np.where(from_cam, 0.98 * BOUNDS[level], 3.0)[:, None]
+    scale = np.where(rng.random((n, 1)) < 0.4, 1.0, 10.0 ** (rng.random((n, 1)) * np.log10(longest / 0.5)) * 0.5)
+    d = d / ln * scale
+    return k, o.astype(f32), d.astype(f32)
+
+
+def _soup_scene(tmp_path):
+    """Small triangles between a camera and a few spheres: a scene whose chunk spheres are bounded at every level."""
+    rng = np.random.default_rng(5)
+    lines = ["camera 0 1.5 -9 0 -.05 1 0 1 0 30", "material .6 .6 .6 .7 .7 .7 .2 .2 .2 8 0 0 0 1", "sphere 0 -3 4 2",
+             "sphere -2 1 1 1", "sphere 2.5 1.2 3 1.2"]
+    n = 1500
+    for _ in range(n):
+        c = np.array([rng.uniform(-6, 6), rng.uniform(-1, 6), rng.uniform(-2, 12)])
+        size = 10.0 ** rng.uniform(-3.5, -2.3)
+        for v in (c, c + rng.normal(size=3) * size, c + rng.normal(size=3) * size):
+            lines.append("vertex %.9g %.9g %.9g" % tuple(v))
+    lines += ["triangle %d %d %d" % (3 * i, 3 * i + 1, 3 * i + 2) for i in range(n)]
+    path = str(tmp_path / "soup.scn")
+    open(path, "w").write("\n".join(lines) + "\n")
+    return skr.parse_scene(path)
+
+
+@pytest.mark.parametrize("name,level", [("dragon.scn", 0), ("dragon.scn", 1), ("dragon.scn", 2), ("soup", 0), ("soup", 2), ("test.scn", 0)])
+def test_no_accepted_pair_is_hidden_by_its_spheres(tmp_path, name, level):
+    sc = _soup_scene(tmp_path) if name == "soup" else _scene(name)
+    n = 300000
+    cs, tris, ch, sup = sc.culling(level)
+    rng = np.random.default_rng(7 + level)
+    k, o, d = _border_rays(rng, sc, tris, n, level)
+    t = tris[k]
+    acc = triangle_accepts(o, d, t[:, 0, :3], t[:, 1, :3], t[:, 2, :3])
+    assert 0.05 * n < acc.sum() < 0.98 * n, "the sample must straddle the border (%d of %d accepted)" % (acc.sum(), n)
+    chunk = k // cs
+    hidden = acc & (sphere_culls(o, d, ch[chunk]) | sphere_culls(o, d, sup[chunk // 8]))
+    assert not hidden.any(), "%d accepted (ray, triangle) pairs would have been culled" % hidden.sum()
+    other = rng.integers(0, ch.shape[0], n)
+    culled = sphere_culls(o, d, ch[other]).mean()
+    if name == "test.scn":
+        # unit-sized triangles 30-40 units from the ray origins: at grazing incidence the reference's binary32 u, v
+        # are off by more than an edge length, no bounded sphere is valid, and the walk stays brute force
+        assert not np.isfinite(ch[:, 3]).any() and culled == 0
+    elif not (name == "soup" and level == 2):  # at |d| <= 256 the soup's slack outgrows its chunks: mostly unbounded
+        assert culled > 0.5, "the spheres must actually cull (%.2f)" % culled
+
+
+def test_levels_nest():
+    """A tighter |d| bound can only shrink a sphere."""
+    sc = _scene("dragon.scn")
+    r = [sc.culling(level)[2][:, 3] for level in range(3)]
+    assert np.all(r[0] <= r[1]) and np.all(r[1] <= r[2]) and np.any(r[0] < r[2])
