@@ -9,6 +9,11 @@ struct f3 {
 };
 
 #define SKR_COUNTER_SHARDS 4096u
+// The GI kernel's group counter is split into SKR_PULL_QUEUES words, SKR_PULL_STRIDE uint32 apart (one word
+// sustains only ~88 atomics/us, and a 1/8 frame already needs 22 000 pulls): queue k hands out the group indices
+// congruent to k mod SKR_PULL_QUEUES.
+#define SKR_PULL_QUEUES 16u
+#define SKR_PULL_STRIDE 256u
 
 struct RenderParams {
 	// image and partition (include/skr.h skr_render_tiles)
@@ -34,7 +39,7 @@ struct RenderParams {
 	unsigned long long *counters; // SKR_COUNTER_SHARDS x {radiance rays, sphere hits shaded, shadow rays, pad}
 	// parent-queue pipeline (render_wave.hip: skr_primary_kernel -> skr_gi_kernel -> skr_resolve_kernel)
 	float4 *parents;    // 4 x float4 per primary hit: co.xyz N.x | N.yz direct.xy | direct.z kd.xyz | pixel, out_pix, -, -
-	uint32_t *qctr;     // [0] number of parents appended, [1] next group to hand out
+	uint32_t *qctr;     // [0] number of parents appended, [SKR_PULL_STRIDE * (1 + k)] next group of pull queue k
 	float *slot0_scratch; // per-wave level-1 contribution slots of the GI kernel (behind the parent records)
 	float *acc;         // float3 per output pixel: the running `image[y][x] += shade(...)` of main.cpp:162 (AA only)
 	uint32_t aa_index;  // which AA sample this launch traces

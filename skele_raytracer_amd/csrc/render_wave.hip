@@ -1066,22 +1066,28 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 	uint32_t G = (n_parents / (slots * 8u)) & ~7u;
 	G = G < 8u ? 8u : (G > (uint32_t) w.par0_max ? (uint32_t) w.par0_max : G);
 	const uint32_t n_groups = (n_parents + G - 1) / G;
-	// one group per atomic: with G adapting to the queue there are at most ~8 pulls per wave slot and
-	// frame, far below what one word sustains (~88 atomics/us)
-	const uint32_t CH = 1u;
+	// One group per atomic, and SKR_PULL_QUEUES counters instead of one: a single word sustains ~88 atomics/us,
+	// which 3072 waves pulling 8-parent groups exceed (a 1/8 frame needs 22 000 pulls: 0.25 ms of a 0.47 ms
+	// kernel was spent queueing for that word).  Queue k owns the group indices congruent to k mod K (every queue
+	// sweeps the frame front to back, like the single counter did); a wave starts at
+	// queue (its index mod K) and moves on to the next one when its queue runs dry, until all K did.
+	const uint32_t K = SKR_PULL_QUEUES;
+	uint32_t qk = (blockIdx.x * 4u + (uint32_t) wave) % K, dry = 0;
 	Counters cn{0, 0, 0};
 	STAMP_DECL;
-	uint32_t g = 0, g_end = 0;
 	for(;;)
 	{
-		if(g == g_end)
-		{
+		uint32_t g;
+		for(;;)
+		{ // wave-uniform
 			uint32_t g0 = 0;
-			if(lane == 0) g0 = atomicAdd(&p.qctr[1], CH);
-			g = (uint32_t) __builtin_amdgcn_readfirstlane((int) g0);
-			if(g >= n_groups) break;
-			g_end = g + CH < n_groups ? g + CH : n_groups;
+			if(lane == 0) g0 = atomicAdd(&p.qctr[SKR_PULL_STRIDE * (1u + qk)], 1u);
+			g = (uint32_t) __builtin_amdgcn_readfirstlane((int) g0) * K + qk;
+			if(g < n_groups) break;
+			qk = qk + 1u == K ? 0u : qk + 1u;
+			if(++dry == K) break;
 		}
+		if(dry == K) break;
 		// A group is G consecutive queue entries (screen neighbours: coherent rays, 6 % faster on a full
 		// frame) — unless there are fewer than ~12 groups per wave slot: then one run of deep ground pixels
 		// (8 x 273 rays) decides the frame time, and group g takes parents g, g + n_groups, g + 2 n_groups, ...
@@ -1125,7 +1131,6 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 		}
 		wave_lds_fence();
 		STAMP(7);
-		g++;
 	}
 #if defined(SKR_STAMPS) && SKR_STAMPS
 	if(p.counters && lane == 0)
@@ -1291,7 +1296,7 @@ hipError_t skr_launch_queue(const RenderParams &p_in, hipStream_t stream, const 
 	for(int s = 0; s < nsamp; s++)
 	{
 		p.aa_index = (uint32_t) s;
-		hipError_t e = hipMemsetAsync(p.qctr, 0, 2 * sizeof(uint32_t), stream);
+		hipError_t e = hipMemsetAsync(p.qctr, 0, (SKR_PULL_QUEUES + 1) * SKR_PULL_STRIDE * sizeof(uint32_t), stream);
 		if(e != hipSuccess) return e;
 		hipLaunchKernelGGL(skr_primary_kernel, grid1, dim3(256), lds1, stream, p);
 		e = hipGetLastError();
