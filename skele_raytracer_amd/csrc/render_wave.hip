@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 	// parents per group: as many as keep ~8 groups per wave slot, between 8 and the table's 32 (big groups
 	// fill the 56-wide activation batches; small queues need small groups to balance)
 	const uint32_t slots = gridDim.x * 4u;
-	uint32_t G = (n_parents / (slots * 8u)) & ~7u;
+	uint32_t G = (n_parents / (slots * p.gi_groups_per_slot)) & ~(p.gi_group_round - 1u);
 	G = G < 8u ? 8u : (G > (uint32_t) w.par0_max ? (uint32_t) w.par0_max : G);
 	const uint32_t n_groups = (n_parents + G - 1) / G;
 	// One group per atomic, and SKR_PULL_QUEUES counters instead of one: a single word sustains ~88 atomics/us,
@@ -1121,11 +1121,31 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 		run_group<DEPTH>(w, gp, q1, q2, cn STAMP_PASS);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's slot stores are complete
 		__builtin_amdgcn_wave_barrier();
+		STAMP(6); // (diagnostic builds: 6 = store drain, 7 = slot sums + emit)
 		if(lane < gp)
 		{ // raytrace.h:133 + :213: the N terms strictly in child order
 			const float *s = w.slot0_g + lane * 3 * w.N;
 			f3 total = mk3(0, 0, 0);
-			for(int i = 0; i < w.N; i++) total = total + mk3(g_load(s + 3 * i), g_load(s + 3 * i + 1), g_load(s + 3 * i + 2));
+			// 16 children per trip to L2: all their loads are issued before the first add (the adds stay in child
+			// order).  One trip per child made this the critical path of small queues: 16 x ~1 us per group.
+			for(int i0 = 0; i0 < w.N; i0 += 16)
+			{
+				float v[16][3];
+#pragma unroll
+				for(int k = 0; k < 16; k++)
+				{
+					const int i = (i0 + k < w.N) ? i0 + k : w.N - 1;
+					v[k][0] = g_load(s + 3 * i);
+					v[k][1] = g_load(s + 3 * i + 1);
+					v[k][2] = g_load(s + 3 * i + 2);
+				}
+#pragma unroll
+				for(int k = 0; k < 16; k++)
+				{
+					const f3 sum = total + mk3(v[k][0], v[k][1], v[k][2]);
+					if(i0 + k < w.N) total = sum;
+				}
+			}
 			total = total / (float) w.N;
 			emit_sample(p, out_pix, (direct0 / (float) 3.14159265358979323846 + total * 2.0f) * kd0);
 		}
@@ -1288,6 +1308,10 @@ static hipError_t launch_gi(const RenderParams &p, size_t lds, hipStream_t strea
 hipError_t skr_launch_queue(const RenderParams &p_in, hipStream_t stream, const SkrTimingHook *hook)
 {
 	RenderParams p = p_in;
+	p.gi_groups_per_slot = 8u;
+	p.gi_group_round = 8u;
+	if(const char *e = getenv("SKR_GPS")) p.gi_groups_per_slot = (uint32_t) atoi(e) > 0 ? (uint32_t) atoi(e) : 8u;
+	if(const char *e = getenv("SKR_GROUND")) p.gi_group_round = (uint32_t) atoi(e) == 4u ? 4u : 8u;
 	const int nsamp = p.grid_size > 0 ? p.grid_size * p.grid_size : 1;
 	const size_t lds1 = ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 32;
 	const bool occ3 = wave_occ_for(p) == 3;
