@@ -339,3 +339,23 @@ def test_triangle_soup_matches_oracle(gpu, oracle, tmp_path, n_tris, with_sphere
     compare(rgb.cpu().numpy(), rgbf.cpu().numpy(), o_rgb, o_f, "soup %d" % n_tris)
     black = int((o_rgb.reshape(-1, 3).sum(axis=1) == 0).sum())
     assert black > 10, "the soup must actually cover pixels (%d black)" % black
+
+
+@pytest.mark.parametrize("name,scn,kw,rows", [
+    ("config2_jsample5", "spheres2.scn", dict(jsample=5, shadow=True, seed=9), None),
+    ("config3_gillum16", "spheres2.scn", dict(gillum=16, shadow=True, seed=20261004), None),
+    ("config4_dragon", "dragon.scn", dict(gillum=16), None),        # 2e10 brute-force triangle tests on the CPU side: ~20 s on the box
+], ids=["config2", "config3", "config4"])
+def test_whole_frames_of_the_baseline_configs_against_oracle(gpu, oracle, name, scn, kw, rows):
+    """BASELINE.json configs[1..3] at 1920x1080: every pixel of the frame bit for bit against the oracle, u8 and
+    float, plus the ray counters (config 4: the culled triangle walk against the oracle's brute-force one)."""
+    w, h = 1920, 1080
+    g_rgb, g_f, cnt = gpu_render(scn, w, h, **kw)
+    y0, y1 = rows if rows else (0, h)
+    o_rgb, o_f, st = oracle.render(scene_path(scn), w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, y0=y0, y1=y1, **kw)
+    compare(g_rgb[y0:y1], g_f[y0:y1], o_rgb, o_f, name)
+    if rows is None:
+        assert cnt["radiance_rays"] == int(st[0]) and cnt["sphere_hits"] == int(st[1])
+    else:
+        black = int((o_rgb.reshape(-1, 3).sum(axis=1) == 0).sum())
+        assert black > 20000, "the band must cross the dragon (%d black pixels)" % black
