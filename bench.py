@@ -48,7 +48,13 @@ def cpu_baseline():
         rays += int(st[0])
         frames += 1
     dt = time.perf_counter() - t0
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "cpu_model": model,
             "ms_per_frame": dt / frames * 1e3,
             "sample": "oracle/liboracle.so (C restatement of the reference path, gcc -O2, OpenMP %d threads = this box's cgroup CPU "
                       "quota), %d whole frames of the same workload: %d radiance rays in %.2f s" % (cores, frames, rays, dt)}
