@@ -64,7 +64,7 @@ def lib():
     L.skr_scene_destroy.restype = None
     L.skr_scene_get_info.argtypes = [vp, C.POINTER(CSceneInfo)]
     L.skr_scene_get_arrays.argtypes = [vp, vp, vp, vp]
-    L.skr_scene_get_culling.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp, vp, vp]
+    L.skr_scene_get_culling.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp, vp, vp, vp]
     L.skr_options_default.argtypes = [C.POINTER(COptions)]
     L.skr_options_default.restype = None
     L.skr_radiance_ray_count.argtypes = [C.POINTER(COptions)]
@@ -149,14 +149,17 @@ class Scene:
         return s, t, l
 
     def culling(self, level=0):
-        """(chunk_size, device_tris [n,3,4], chunk_spheres [nc,4], super_spheres [ns,4]) — include/skr.h skr_scene_get_culling."""
-        cs, nc, ns = C.c_int32(), C.c_int32(), C.c_int32()
-        _check(lib().skr_scene_get_culling(self.h, level, C.byref(cs), C.byref(nc), C.byref(ns), None, None, None), "skr_scene_get_culling")
+        """(chunk_size, device_tris [n,3,4], node_spheres [nn,4], node_links [nn,4] int32, chunk_spheres [nc,4]) —
+        include/skr.h skr_scene_get_culling."""
+        cs, nn, nc = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(lib().skr_scene_get_culling(self.h, level, C.byref(cs), C.byref(nn), C.byref(nc), None, None, None, None), "skr_scene_get_culling")
         tris = np.zeros((self.info.n_triangles, 3, 4), np.float32)
+        sph = np.zeros((nn.value, 4), np.float32)
+        links = np.zeros((nn.value, 4), np.int32)
         ch = np.zeros((nc.value, 4), np.float32)
-        sup = np.zeros((ns.value, 4), np.float32)
-        _check(lib().skr_scene_get_culling(self.h, level, None, None, None, tris.ctypes.data, ch.ctypes.data, sup.ctypes.data), "skr_scene_get_culling")
-        return cs.value, tris, ch, sup
+        _check(lib().skr_scene_get_culling(self.h, level, None, None, None, tris.ctypes.data, sph.ctypes.data, links.ctypes.data, ch.ctypes.data),
+               "skr_scene_get_culling")
+        return cs.value, tris, sph, links, ch
 
     @staticmethod
     def from_arrays(spheres, triangles, point_lights, camera, background=(0, 0, 0), ambient=(0, 0, 0)):

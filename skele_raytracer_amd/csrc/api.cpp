@@ -96,7 +96,7 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	r->off_chunks = 4 * ns + nl2 + nt3;
 	r->chunk_size = scene->tri_chunk_size;
 	r->chunk_stride = scene->tri_chunk_stride;
-	r->n_chunks = scene->info.n_triangles ? (scene->info.n_triangles + r->chunk_size - 1) / r->chunk_size : 0; // then a pad, the second-level spheres, a pad
+	r->n_chunks = scene->info.n_triangles ? scene->tri_node_count : 0; // nodes of the chunk tree (two float4 each, + a pad node)
 	const size_t total = 4 * ns + nl2 + nt3 + nch;
 	std::vector<skr_f4> blob(total > 0 ? total : 1);
 	if(ns)

@@ -27,10 +27,10 @@ struct RenderParams {
 	// SoA scene in HBM (scene_host.h)
 	int32_t n_spheres, n_tris, n_lights;
 	const float4 *sph_geom, *sph_amb, *sph_kd, *sph_ks, *lights, *tris;
-	const float4 *tri_chunks; // centre, radius^2 of the conservative sphere of every tri_chunk_size triangles (+1 pad), then the second level
+	const float4 *tri_chunks; // the chunk tree of the triangle walk (scene_host.h): 2 float4 per node, depth-first, skip links
 	int32_t tri_chunk_size;
 	uint32_t gi_groups_per_slot, gi_group_round; // GI kernel group-size policy (set by skr_launch_queue)
-	int32_t n_tri_chunks;     // 0 = culling off (ray directions longer than the bounds were built for)
+	int32_t n_tri_chunks;     // its node count; 0 = culling off (ray directions longer than the bounds were built for)
 	// utils.h:26-34 Options + scene.use_shadows
 	int32_t monte_carlo, num_path_traces, grid_size, max_depth, use_shadows;
 	uint32_t seed_lo, seed_hi;

@@ -210,35 +210,89 @@ void skr_scene::build_triangle_chunk_level(double d_max, std::vector<skr_f4> &tr
 		if(unbounded || !(r2 == r2)) r2f = INFINITY;
 		tri_chunks[c] = {(float) cx, (float) cy, (float) cz, r2f};
 	}
-	// second level: one sphere around every SKR_TRI_SUPER consecutive chunk spheres (a line that touches a
-	// chunk sphere touches this one), stored behind the chunk entries: [nc + 1 + s]
-	const int nsup = (nc + SKR_TRI_SUPER - 1) / SKR_TRI_SUPER;
-	tri_chunks.resize((size_t) nc + 1 + nsup + 1, skr_f4{0.0f, 0.0f, 0.0f, INFINITY});
-	for(int s = 0; s < nsup; s++)
+	// Upper levels: one sphere around every SKR_TRI_SUPER consecutive nodes of the level below (a line that touches a
+	// child's sphere touches this one), until a single root is left.  The levels above the chunks are laid out
+	// depth-first with skip links — node = {centre, radius^2} {skip, first chunk, chunk count, height} — so that the
+	// device walks them with one wave-uniform index and no stack: touched -> next entry, missed -> entry [skip];
+	// a node of height 1 runs over its (contiguous) chunk spheres in a tight loop.  The chunk spheres follow the
+	// nodes in the same array.
+	struct Ball { double x, y, z, r; bool unbounded; };
+	std::vector<std::vector<Ball>> levels(1);
+	for(int c = 0; c < nc; c++)
 	{
-		const int c0 = s * SKR_TRI_SUPER, c1 = std::min(nc, c0 + SKR_TRI_SUPER);
-		double cx = 0, cy = 0, cz = 0, mag = 0;
-		bool unbounded = false;
-		for(int c = c0; c < c1; c++)
-		{
-			cx += tri_chunks[c].x; cy += tri_chunks[c].y; cz += tri_chunks[c].z;
-			if(!(tri_chunks[c].w < INFINITY)) unbounded = true;
-		}
-		cx /= (c1 - c0); cy /= (c1 - c0); cz /= (c1 - c0);
-		double rad = 0;
-		for(int c = c0; c < c1; c++)
-		{
-			const double rc = std::sqrt((double) tri_chunks[c].w) * (1 + 1e-6);
-			rad = std::max(rad, norm(tri_chunks[c].x - cx, tri_chunks[c].y - cy, tri_chunks[c].z - cz) + rc);
-			mag = std::max(mag, std::max(std::fabs((double) tri_chunks[c].x), std::max(std::fabs((double) tri_chunks[c].y), std::fabs((double) tri_chunks[c].z))) + rc);
-		}
-		rad = rad * (1 + 1e-4) + 1e-5 * (1 + mag);
-		const double r2 = rad * rad;
-		float r2f = (float) r2;
-		if((double) r2f < r2) r2f = std::nextafterf(r2f, INFINITY);
-		if(unbounded || !(r2 == r2)) r2f = INFINITY;
-		tri_chunks[(size_t) nc + 1 + s] = {(float) cx, (float) cy, (float) cz, r2f};
+		const skr_f4 &s = tri_chunks[c];
+		levels[0].push_back({s.x, s.y, s.z, std::sqrt((double) s.w), !(s.w < INFINITY)});
 	}
+	do
+	{
+		const std::vector<Ball> &lo = levels.back();
+		std::vector<Ball> up;
+		for(size_t c0 = 0; c0 < lo.size(); c0 += SKR_TRI_SUPER)
+		{
+			const size_t c1 = std::min(lo.size(), c0 + SKR_TRI_SUPER);
+			Ball b{0, 0, 0, 0, false};
+			for(size_t c = c0; c < c1; c++)
+			{
+				b.x += lo[c].x; b.y += lo[c].y; b.z += lo[c].z;
+				b.unbounded = b.unbounded || lo[c].unbounded;
+			}
+			b.x /= (double) (c1 - c0); b.y /= (double) (c1 - c0); b.z /= (double) (c1 - c0);
+			double mag = 0;
+			for(size_t c = c0; c < c1; c++)
+			{
+				const double rc = lo[c].r * (1 + 1e-6);
+				b.r = std::max(b.r, norm(lo[c].x - b.x, lo[c].y - b.y, lo[c].z - b.z) + rc);
+				mag = std::max(mag, std::max(std::fabs(lo[c].x), std::max(std::fabs(lo[c].y), std::fabs(lo[c].z))) + rc);
+			}
+			b.r = b.r * (1 + 1e-4) + 1e-5 * (1 + mag); // room for the float centre and the device-side test's own rounding
+			up.push_back(b);
+		}
+		levels.push_back(up);
+	} while(levels.back().size() > 1);
+	std::vector<skr_f4> nodes;
+	auto f4i = [](int32_t a, int32_t b, int32_t c, int32_t d) {
+		skr_f4 v;
+		memcpy(&v.x, &a, 4); memcpy(&v.y, &b, 4); memcpy(&v.z, &c, 4); memcpy(&v.w, &d, 4);
+		return v;
+	};
+	struct Emit {
+		const std::vector<std::vector<Ball>> &levels;
+		std::vector<skr_f4> &nodes;
+		int chunk, nt;
+		decltype(f4i) &pack;
+		void run(int level, size_t idx)
+		{
+			const Ball &b = levels[level][idx];
+			const double r2 = b.r * b.r;
+			float r2f = (float) r2;
+			if((double) r2f < r2) r2f = std::nextafterf(r2f, INFINITY);
+			if(b.unbounded || !(r2 == r2)) r2f = INFINITY;
+			const size_t me = nodes.size();
+			nodes.push_back({(float) b.x, (float) b.y, (float) b.z, r2f});
+			nodes.push_back({0, 0, 0, 0});
+			int first = 0, count = 0;
+			if(level == 1)
+			{
+				first = (int) idx * SKR_TRI_SUPER;
+				count = (int) std::min(levels[0].size(), (size_t) first + SKR_TRI_SUPER) - first;
+			}
+			else
+			{
+				const size_t c0 = idx * SKR_TRI_SUPER, c1 = std::min(levels[level - 1].size(), c0 + SKR_TRI_SUPER);
+				for(size_t c = c0; c < c1; c++) run(level - 1, c);
+			}
+			nodes[me + 1] = pack((int32_t) (nodes.size() / 2), first, count, level);
+		}
+	};
+	Emit emit{levels, nodes, tri_chunk_size, nt, f4i};
+	emit.run((int) levels.size() - 1, 0);
+	// one pad node so that the walk may prefetch past the end, then the chunk spheres (+ their pad entry)
+	const int32_t n_nodes = (int32_t) (nodes.size() / 2);
+	nodes.push_back({0.0f, 0.0f, 0.0f, INFINITY});
+	nodes.push_back(f4i(n_nodes + 1, 0, 0, 0));
+	nodes.insert(nodes.end(), tri_chunks.begin(), tri_chunks.end());
+	tri_node_count = n_nodes;
+	tri_chunks.swap(nodes);
 }
 
 static void set_camera(skr_scene_info &info, const float p[3], const float d[3], const float u[3], float ha)
@@ -480,19 +534,23 @@ int skr_scene_get_arrays(const skr_scene *scene, float *spheres, float *triangle
 	return SKR_OK;
 }
 
-int skr_scene_get_culling(const skr_scene *scene, int32_t level, int32_t *chunk_size, int32_t *n_chunks, int32_t *n_super,
-						  float *device_tris, float *chunk_spheres, float *super_spheres)
+int skr_scene_get_culling(const skr_scene *scene, int32_t level, int32_t *chunk_size, int32_t *n_nodes, int32_t *n_chunks,
+						  float *device_tris, float *node_spheres, int32_t *node_links, float *chunk_spheres)
 {
 	if(!scene || level < 0 || level >= SKR_CULL_LEVELS) return SKR_ERR_ARG;
-	const skr_f4 *base = scene->tri_chunks.data() + (size_t) level * scene->tri_chunk_stride;
-	const int nt = scene->info.n_triangles, cs = scene->tri_chunk_size;
-	const int nc = nt ? (nt + cs - 1) / cs : 0, nsup = (nc + SKR_TRI_SUPER - 1) / SKR_TRI_SUPER;
+	const int nt = scene->info.n_triangles, nn = nt ? scene->tri_node_count : 0, cs = scene->tri_chunk_size;
+	const int nc = nt ? (nt + cs - 1) / cs : 0;
 	if(chunk_size) *chunk_size = cs;
+	if(n_nodes) *n_nodes = nn;
 	if(n_chunks) *n_chunks = nc;
-	if(n_super) *n_super = nsup;
 	if(device_tris && nt) memcpy(device_tris, scene->tris.data(), (size_t) nt * 48);
-	if(chunk_spheres && nc) memcpy(chunk_spheres, base, (size_t) nc * 16);
-	if(super_spheres && nsup) memcpy(super_spheres, base + nc + 1, (size_t) nsup * 16);
+	const skr_f4 *base = scene->tri_chunks.data() + (size_t) level * scene->tri_chunk_stride;
+	for(int i = 0; i < nn; i++)
+	{
+		if(node_spheres) memcpy(node_spheres + 4 * (size_t) i, base + 2 * (size_t) i, 16);
+		if(node_links) memcpy(node_links + 4 * (size_t) i, base + 2 * (size_t) i + 1, 16);
+	}
+	if(chunk_spheres && nc) memcpy(chunk_spheres, base + 2 * ((size_t) nn + 1), (size_t) nc * 16);
 	return SKR_OK;
 }
 

@@ -108,44 +108,55 @@ SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float t
 {
 	bool hit = false;
 	if(sv.nchunks > 0)
-	{ // chunked walk: a line that misses a chunk's conservative sphere cannot pass the test for any of its 32
-	  // triangles (scene_host.cpp build_triangle_chunks), so a chunk that no lane's line touches is skipped whole
+	{ // A line that misses a conservative sphere cannot pass the test for any triangle below it (scene_host.cpp
+	  // build_triangle_chunks), so a node or chunk that no lane's line touches is skipped whole.  The levels above
+	  // the chunks are stored depth-first with skip links: one wave-uniform index, no stack; both possible
+	  // successors are fetched (scalar loads) while the sphere is tested.
 		const float dd = r.two_a * 0.5f; // dot(d, d)
-		const int nsup = (sv.nchunks + SKR_TRI_SUPER - 1) / SKR_TRI_SUPER;
-		const float4 *sup = sv.chunks + sv.nchunks + 1; // second-level spheres
-		float4 sp_next = sup[0];
-		for(int s = 0; s < nsup; s++)
+		int i = 0;
+		const float4 *chunk_sph = sv.chunks + 2 * (sv.nchunks + 1); // behind the nodes and their pad
+		float4 sp = sv.chunks[0], lk = sv.chunks[1];
+		while(i < sv.nchunks)
 		{
-			const float4 sp = sp_next;
-			sp_next = sup[s + 1]; // padded
-			const f3 es = ld3(sp) - r.o;
-			const f3 crs = cross3(es, r.d);
-			if(!__any(!hit && !(dot3(crs, crs) > sp.w * dd))) continue; // no lane's line touches any of its chunk spheres
-			const int c0 = s * SKR_TRI_SUPER, c1 = (c0 + SKR_TRI_SUPER < sv.nchunks) ? c0 + SKR_TRI_SUPER : sv.nchunks;
-			float4 c_next = sv.chunks[c0];
-			for(int c = c0; c < c1; c++)
-			{
-				const float4 ch = c_next;
-				c_next = sv.chunks[c + 1];
-				const f3 e = ld3(ch) - r.o;
-				const f3 cr = cross3(e, r.d);
-				const bool maybe = !hit && !(dot3(cr, cr) > ch.w * dd); // |e x d|^2 <= R^2 |d|^2; NaN => test the chunk
-				if(__any(maybe))
+			const int i_out = __float_as_int(lk.x);
+			const float4 sp_in = sv.chunks[2 * i + 2], lk_in = sv.chunks[2 * i + 3];       // first child, or the next node after a leaf
+			const float4 sp_out = sv.chunks[2 * i_out], lk_out = sv.chunks[2 * i_out + 1]; // next sibling (padded past the end)
+			const f3 e = ld3(sp) - r.o;
+			const f3 cr = cross3(e, r.d);
+			const bool maybe = !hit && !(dot3(cr, cr) > sp.w * dd); // |e x d|^2 <= R^2 |d|^2; NaN => enter the node
+			const bool enter = __any(maybe);
+			const int count = __float_as_int(lk.z);
+			if(enter && count > 0)
+			{ // height 1: its chunk spheres are contiguous — tight loop, next sphere prefetched
+				const int c0 = __float_as_int(lk.y), c1 = c0 + count;
+				float4 c_next = chunk_sph[c0];
+				for(int c = c0; c < c1; c++)
 				{
-					const int i0 = c * sv.chunk, i1 = (i0 + sv.chunk < sv.nt) ? i0 + sv.chunk : sv.nt;
-					float4 n0 = sv.tris[3 * i0], n1 = sv.tris[3 * i0 + 1], n2 = sv.tris[3 * i0 + 2];
-					for(int i = i0; i < i1; i++)
+					const float4 ch = c_next;
+					c_next = chunk_sph[c + 1];
+					const f3 ec = ld3(ch) - r.o;
+					const f3 crc = cross3(ec, r.d);
+					const bool mine = !hit && !(dot3(crc, crc) > ch.w * dd);
+					if(__any(mine))
 					{
-						const f3 v0 = ld3(n0), e1 = ld3(n1), e2 = ld3(n2);
-						n0 = sv.tris[3 * i + 3];
-						n1 = sv.tris[3 * i + 4];
-						n2 = sv.tris[3 * i + 5];
-						float t;
-						if(maybe && !hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
+						const int i0 = c * sv.chunk, i1 = (i0 + sv.chunk < sv.nt) ? i0 + sv.chunk : sv.nt;
+						float4 n0 = sv.tris[3 * i0], n1 = sv.tris[3 * i0 + 1], n2 = sv.tris[3 * i0 + 2];
+						for(int k = i0; k < i1; k++)
+						{
+							const f3 v0 = ld3(n0), e1 = ld3(n1), e2 = ld3(n2);
+							n0 = sv.tris[3 * k + 3];
+							n1 = sv.tris[3 * k + 4];
+							n2 = sv.tris[3 * k + 5];
+							float t;
+							if(mine && !hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
+						}
 					}
 				}
+				if(__all(hit)) break;
 			}
-			if(__all(hit)) break;
+			i = enter ? i + 1 : i_out;
+			sp = enter ? sp_in : sp_out;
+			lk = enter ? lk_in : lk_out;
 		}
 		return hit;
 	}

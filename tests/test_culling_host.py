@@ -1,6 +1,6 @@
 """Host logic of the triangle culling hierarchy (csrc/scene_host.cpp build_triangle_chunks) — no GPU.
 
-The device walk skips a chunk of triangles when `|e x d|^2 > R^2 |d|^2` for its sphere.  These tests restate both
+The device walk skips a node of the chunk tree (and every triangle below it) when `|e x d|^2 > R^2 |d|^2` for its sphere.  These tests restate both
 sides in numpy binary32 with the device's operation order — the acceptance test of utils.h:181-213
 (device_math.h triangle_hit) and the sphere test of shade_common.h any_triangle_closer — and check, on rays aimed
 at the borders of the accept regions, that no accepted (ray, triangle) pair is ever hidden by its spheres.
@@ -52,11 +52,31 @@ def _scene(name):
     return skr.parse_scene(scene_path(name))
 
 
+def tree_parents(links):
+    """Parent index of every node of the depth-first, skip-linked tree (root: -1), and the height-1 node of every chunk."""
+    n = links.shape[0]
+    parent = np.full(n, -1, np.int64)
+    stack = []
+    for i in range(n):
+        while stack and links[stack[-1], 0] <= i:
+            stack.pop()
+        if stack:
+            parent[i] = stack[-1]
+        if links[i, 2] == 0:
+            stack.append(i)
+    leaves = np.nonzero(links[:, 2] > 0)[0]
+    n_chunks = int((links[leaves, 1] + links[leaves, 2]).max()) if leaves.size else 0
+    node_of_chunk = np.full(n_chunks, -1, np.int64)
+    for i in leaves:
+        node_of_chunk[links[i, 1]:links[i, 1] + links[i, 2]] = i
+    return parent, node_of_chunk
+
+
 @pytest.mark.parametrize("name", ["dragon.scn", "test.scn", "spheres1.scn"])
 def test_device_triangles_are_a_permutation_of_the_file_triangles(name):
     sc = _scene(name)
     _, raw, _ = sc.arrays()
-    cs, tris, ch, sup = sc.culling()
+    cs, tris, sph, links, ch = sc.culling()
     n = raw.shape[0]
     want = np.concatenate([raw[:, 0:3], raw[:, 3:6] - raw[:, 0:3], raw[:, 6:9] - raw[:, 0:3]], axis=1)  # utils.h:183-184
     got = tris[:, :, :3].reshape(n, 9)
@@ -64,26 +84,55 @@ def test_device_triangles_are_a_permutation_of_the_file_triangles(name):
     key = lambda a: a[np.lexsort(a.T[::-1])]
     assert np.array_equal(key(want), key(got))
     assert cs == (8 if sc.info.n_spheres == 0 else 32)
-    assert ch.shape[0] == (n + cs - 1) // cs and sup.shape[0] == (ch.shape[0] + 7) // 8
+
+
+@pytest.mark.parametrize("name", ["dragon.scn", "test.scn", "spheres1.scn"])
+def test_tree_shape(name):
+    """Chunks are consecutive runs of chunk_size device triangles; the nodes above them are in depth-first order with
+    skip links: every chunk sits under exactly one height-1 node, a node has at most 8 children and its skip link
+    closes exactly its subtree."""
+    sc = _scene(name)
+    cs, tris, sph, links, ch = sc.culling()
+    n, nt = links.shape[0], tris.shape[0]
+    assert ch.shape[0] == (nt + cs - 1) // cs
+    parent, node_of_chunk = tree_parents(links)
+    assert np.all(node_of_chunk >= 0) and node_of_chunk.shape[0] == ch.shape[0]
+    leaves = np.nonzero(links[:, 2] > 0)[0]
+    assert np.array_equal(links[leaves, 1], np.arange(leaves.size) * 8)          # consecutive, in order
+    assert np.all(links[leaves[:-1], 2] == 8) and 0 < links[leaves[-1], 2] <= 8
+    assert np.all(links[leaves, 0] == leaves + 1) and np.all(links[leaves, 3] == 1)
+    assert links[0, 0] == n and parent[0] == -1 and np.all(parent[1:] >= 0)
+    inner = np.nonzero(links[:, 2] == 0)[0]
+    kids = np.bincount(parent[1:], minlength=n) if n > 1 else np.zeros(n, np.int64)
+    assert np.all(kids[inner] >= 1) and np.all(kids[inner] <= 8) and np.all(kids[leaves] == 0)
+    assert np.all(links[1:, 3] == links[parent[1:], 3] - 1)                       # heights step by one
+    assert np.all(links[1:, 0] <= links[parent[1:], 0])                           # a subtree closes inside its parent's
 
 
 @pytest.mark.parametrize("name", ["dragon.scn", "test.scn", "spheres1.scn"])
 def test_spheres_contain_their_accept_regions_and_children(name):
     sc = _scene(name)
-    cs, tris, ch, sup = sc.culling()
+    cs, tris, sph, links, ch = sc.culling()
+    parent, node_of_chunk = tree_parents(links)
     t = tris.astype(np.float64)
     v0, e1, e2 = t[:, 0, :3], t[:, 1, :3], t[:, 2, :3]
     corners = np.stack([v0, v0 - e1, v0 + e2], axis=1)  # the mirrored triangle the reference's test accepts
-    chunk_of = np.arange(t.shape[0]) // cs
-    c = ch[chunk_of].astype(np.float64)
+    c = ch[np.arange(t.shape[0]) // cs].astype(np.float64)
     dist = np.linalg.norm(corners - c[:, None, :3], axis=2).max(axis=1)
     finite = np.isfinite(c[:, 3])
     assert np.all(dist[finite] < np.sqrt(c[finite, 3])), "an accept region sticks out of its chunk sphere"
-    s = sup[np.arange(ch.shape[0]) // 8].astype(np.float64)
-    both = np.isfinite(s[:, 3])
-    assert np.all(np.isfinite(ch[both, 3])), "an unbounded chunk under a bounded second-level sphere"
-    reach = np.linalg.norm(ch[both, :3].astype(np.float64) - s[both, :3], axis=1) + np.sqrt(ch[both, 3].astype(np.float64))
-    assert np.all(reach < np.sqrt(s[both, 3]))
+
+    def inside(child_sph, parent_sph, what):
+        both = np.isfinite(parent_sph[:, 3])
+        assert np.all(np.isfinite(child_sph[both, 3])), "an unbounded %s under a bounded node" % what
+        reach = np.linalg.norm(child_sph[both, :3].astype(np.float64) - parent_sph[both, :3].astype(np.float64), axis=1) \
+            + np.sqrt(child_sph[both, 3].astype(np.float64))
+        assert np.all(reach < np.sqrt(parent_sph[both, 3].astype(np.float64))), "a %s sticks out of its node" % what
+
+    inside(ch, sph[node_of_chunk], "chunk")
+    if sph.shape[0] > 1:
+        child = np.arange(1, sph.shape[0])
+        inside(sph[child], sph[parent[child]], "node")
     # the Morton order must have made the chunks small: median chunk radius well below the mesh extent
     extent = np.linalg.norm(v0.max(axis=0) - v0.min(axis=0))
     if name == "dragon.scn":
@@ -150,21 +199,27 @@ def _soup_scene(tmp_path):
 def test_no_accepted_pair_is_hidden_by_its_spheres(tmp_path, name, level):
     sc = _soup_scene(tmp_path) if name == "soup" else _scene(name)
     n = 300000
-    cs, tris, ch, sup = sc.culling(level)
+    cs, tris, sph, links, ch = sc.culling(level)
+    parent, node_of_chunk = tree_parents(links)
     rng = np.random.default_rng(7 + level)
     k, o, d = _border_rays(rng, sc, tris, n, level)
     t = tris[k]
     acc = triangle_accepts(o, d, t[:, 0, :3], t[:, 1, :3], t[:, 2, :3])
     assert 0.05 * n < acc.sum() < 0.98 * n, "the sample must straddle the border (%d of %d accepted)" % (acc.sum(), n)
     chunk = k // cs
-    hidden = acc & (sphere_culls(o, d, ch[chunk]) | sphere_culls(o, d, sup[chunk // 8]))
+    hidden = acc & sphere_culls(o, d, ch[chunk])
+    node = node_of_chunk[chunk]
+    while np.any(node >= 0):  # the height-1 node and every ancestor up to the root
+        live = node >= 0
+        hidden[live] |= acc[live] & sphere_culls(o[live], d[live], sph[node[live]])
+        node = np.where(live, parent[np.maximum(node, 0)], -1)
     assert not hidden.any(), "%d accepted (ray, triangle) pairs would have been culled" % hidden.sum()
     other = rng.integers(0, ch.shape[0], n)
     culled = sphere_culls(o, d, ch[other]).mean()
     if name == "test.scn":
         # unit-sized triangles 30-40 units from the ray origins: at grazing incidence the reference's binary32 u, v
         # are off by more than an edge length, no bounded sphere is valid, and the walk stays brute force
-        assert not np.isfinite(ch[:, 3]).any() and culled == 0
+        assert not np.isfinite(sph[:, 3]).any() and not np.isfinite(ch[:, 3]).any() and culled == 0
     elif not (name == "soup" and level == 2):  # at |d| <= 256 the soup's slack outgrows its chunks: mostly unbounded
         assert culled > 0.5, "the spheres must actually cull (%.2f)" % culled
 
@@ -172,5 +227,8 @@ def test_no_accepted_pair_is_hidden_by_its_spheres(tmp_path, name, level):
 def test_levels_nest():
     """A tighter |d| bound can only shrink a sphere."""
     sc = _scene("dragon.scn")
-    r = [sc.culling(level)[2][:, 3] for level in range(3)]
-    assert np.all(r[0] <= r[1]) and np.all(r[1] <= r[2]) and np.any(r[0] < r[2])
+    for which in (2, 4):  # node spheres, chunk spheres
+        r = [sc.culling(level)[which][:, 3] for level in range(3)]
+        assert np.all(r[0] <= r[1]) and np.all(r[1] <= r[2]) and np.any(r[0] < r[2])
+    links = [sc.culling(level)[3] for level in range(3)]
+    assert np.array_equal(links[0], links[1]) and np.array_equal(links[1], links[2])  # one topology, three sets of radii
