@@ -359,3 +359,58 @@ def test_whole_frames_of_the_baseline_configs_against_oracle(gpu, oracle, name, 
     else:
         black = int((o_rgb.reshape(-1, 3).sum(axis=1) == 0).sum())
         assert black > 20000, "the band must cross the dragon (%d black pixels)" % black
+
+
+def _write_bumpy_sphere(path, n_lat, n_lon):
+    """A tessellated, radially displaced sphere of 2*n_lat*n_lon small triangles in front of the camera."""
+    rng = np.random.default_rng(3)
+    lines = ["camera 0 0 -6 0 0 1 0 1 0 30", "background .2 .3 .4"]
+    th = np.linspace(0.02, np.pi - 0.02, n_lat + 1)
+    ph = np.linspace(0, 2 * np.pi, n_lon + 1)
+    rad = 1.5 + 0.05 * rng.random((n_lat + 1, n_lon + 1))
+    rad[:, -1] = rad[:, 0]
+    x = rad * np.sin(th)[:, None] * np.cos(ph)[None, :]
+    y = rad * np.cos(th)[:, None] * np.ones_like(ph)[None, :]
+    z = rad * np.sin(th)[:, None] * np.sin(ph)[None, :]
+    v = np.stack([x, y, z], axis=-1).reshape(-1, 3)
+    lines += ["vertex %.7g %.7g %.7g" % tuple(p) for p in v]
+    idx = lambda i, j: i * (n_lon + 1) + j
+    for i in range(n_lat):
+        for j in range(n_lon):
+            lines.append("triangle %d %d %d" % (idx(i, j), idx(i + 1, j), idx(i, j + 1)))
+            lines.append("triangle %d %d %d" % (idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)))
+    open(path, "w").write("\n".join(lines) + "\n")
+    return 2 * n_lat * n_lon
+
+
+def test_large_mesh_walk_scales_and_stays_exact(gpu, oracle, tmp_path, monkeypatch):
+    """125 000 triangles (12x the dragon): the tree walk must reproduce the brute-force walk on the whole frame and
+    the oracle on a band of rows, and its cost must not follow the triangle count."""
+    import time
+    scn = str(tmp_path / "bumpy.scn")
+    nt = _write_bumpy_sphere(scn, 250, 250)
+    w, h = 1280, 720
+    r = skr.Renderer(skr.parse_scene(scn))
+    opt = skr.Options(w, h)
+    monkeypatch.delenv("SKR_NO_CULL", raising=False)
+    r.render(opt)
+    gpu.cuda.synchronize()
+    t0 = time.perf_counter()
+    a, af = r.render(opt, want_float=True)
+    gpu.cuda.synchronize()
+    t_tree = time.perf_counter() - t0
+    monkeypatch.setenv("SKR_NO_CULL", "1")
+    t0 = time.perf_counter()
+    b, bf = r.render(opt, want_float=True)
+    gpu.cuda.synchronize()
+    t_brute = time.perf_counter() - t0
+    monkeypatch.delenv("SKR_NO_CULL", raising=False)
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    assert np.array_equal(a, b) and np.array_equal(af.cpu().numpy().view(np.uint32), bf.cpu().numpy().view(np.uint32))
+    y0, y1 = 356, 364
+    o_rgb, o_f, _ = oracle.render(scn, w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, y0=y0, y1=y1)
+    compare(a[y0:y1], af.cpu().numpy()[y0:y1], o_rgb, o_f, "bumpy sphere rows")
+    black = int((a.reshape(-1, 3).sum(axis=1) == 0).sum())
+    assert black > 0.05 * w * h, "the mesh must cover a good part of the frame (%d black pixels)" % black
+    print("\n%d triangles %dx%d: tree walk %.2f ms, brute force %.1f ms" % (nt, w, h, t_tree * 1e3, t_brute * 1e3))
+    assert t_tree * 20 < t_brute
