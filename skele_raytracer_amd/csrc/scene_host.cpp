@@ -258,7 +258,6 @@ void skr_scene::build_triangle_chunk_level(double d_max, std::vector<skr_f4> &tr
 	struct Emit {
 		const std::vector<std::vector<Ball>> &levels;
 		std::vector<skr_f4> &nodes;
-		int chunk, nt;
 		decltype(f4i) &pack;
 		void run(int level, size_t idx)
 		{
@@ -284,7 +283,7 @@ void skr_scene::build_triangle_chunk_level(double d_max, std::vector<skr_f4> &tr
 			nodes[me + 1] = pack((int32_t) (nodes.size() / 2), first, count, level);
 		}
 	};
-	Emit emit{levels, nodes, tri_chunk_size, nt, f4i};
+	Emit emit{levels, nodes, f4i};
 	emit.run((int) levels.size() - 1, 0);
 	// one pad node so that the walk may prefetch past the end, then the chunk spheres (+ their pad entry)
 	const int32_t n_nodes = (int32_t) (nodes.size() / 2);

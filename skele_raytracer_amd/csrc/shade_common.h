@@ -19,8 +19,9 @@ struct SceneView {
 	const float4 *lights; // LDS [2i] position [2i+1] colour
 	const float4 *tris; // HBM  [3i] v0 [3i+1] e1 [3i+2] e2
 	int ns, nt, nl;
-	const float4 *chunks; // HBM  conservative sphere (centre, radius^2) per 32 triangles, + 1 pad
-	int nchunks;          // 0 = walk every triangle
+	const float4 *chunks; // HBM  culling data of the triangle walk (scene_host.h): the skip-linked tree, 2 float4 per node,
+	                      //      + a pad node, then one conservative sphere (centre, radius^2) per chunk of triangles
+	int nchunks;          // nodes in the tree; 0 = walk every triangle
 	int chunk;            // triangles per chunk sphere (tri_chunks.h)
 };
 

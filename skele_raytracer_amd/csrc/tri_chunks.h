@@ -9,7 +9,7 @@
 #define SKR_TRI_CHUNK_COHERENT 8
 #define SKR_TRI_CHUNK_MIXED 32
 #ifndef SKR_TRI_SUPER
-#define SKR_TRI_SUPER 8 /* first-level spheres per second-level sphere */
+#define SKR_TRI_SUPER 8 /* children per node of the tree above the chunk spheres */
 #endif
 /* The rounding slack of the triangle test grows with |d| (its |det| >= 1e-5 cut is absolute), so the spheres are
  * built for three bounds on the direction length and the launcher picks the tightest one that covers the frame:
