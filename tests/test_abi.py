@@ -131,3 +131,10 @@ def test_product_never_touches_the_oracle():
                     if re.search(r"liboracle|pyoracle|skr_oracle|oracle/|sko_", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_host_code_is_clean_under_asan_and_ubsan():
+    """The loader (on the reference scenes, malformed and random input), the culling-tree builder and the getters,
+    built with -fsanitize=address,undefined (CPU build; tools/sanitize_host.sh)."""
+    res = subprocess.run(["sh", os.path.join(ROOT, "tools", "sanitize_host.sh")], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "sanitize_host: clean" in res.stdout, res.stdout + res.stderr

@@ -1,0 +1,21 @@
+#!/bin/sh
+# Host code under AddressSanitizer + UBSan (CPU build only; the GPU pool runs no sanitizers): the .scn loader on
+# the reference scenes and on malformed / random input, the culling-tree builder and the array getters.
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p build
+g++ -std=c++17 -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -Iinclude -o build/sanitize_host tools/sanitize_host.cpp skele_raytracer_amd/csrc/scene_host.cpp
+printf 'sphere 1 2\nvertex 1 2\ntriangle 0 1 999999\ntriangle -5 0 1\nmaterial 1\ncamera\npoint_light 1 2 3\nvertex nan inf -inf\nvertex 1e39 0 0\ntriangle 0 0 0\ntriangle 1.7 0.2 2.9\n' > build/bad1.scn
+: > build/empty.scn
+python3 - <<'PY'
+import random
+random.seed(1)
+words = ["sphere", "vertex", "triangle", "material", "camera", "point_light", "directional_light", "ambient_light", "background",
+         "max_depth", "film_resolution", "spherical_fog", "normal", "max_vertices", "max_normals", "#", "output_image"]
+with open("build/fuzz.scn", "w") as f:
+    for _ in range(3000):
+        f.write(random.choice(words) + " " + " ".join(random.choice(["1", "-2.5", "1e30", "nan", "x", "0", "3", "100000", "-1", ""]) for _ in range(random.randint(0, 16))) + "\n")
+PY
+./build/sanitize_host tests/golden/scenes/*.scn build/bad1.scn build/empty.scn build/fuzz.scn /nonexistent.scn > build/sanitize_host.log 2>&1
+if grep -q "runtime error\|Sanitizer" build/sanitize_host.log; then grep "runtime error\|Sanitizer" build/sanitize_host.log; exit 1; fi
+echo "sanitize_host: clean"
