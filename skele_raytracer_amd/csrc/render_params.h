@@ -12,7 +12,9 @@ struct f3 {
 // The GI kernel's group counter is split into SKR_PULL_QUEUES words, SKR_PULL_STRIDE uint32 apart (one word
 // sustains only ~88 atomics/us, and a 1/8 frame already needs 22 000 pulls): queue k hands out the group indices
 // congruent to k mod SKR_PULL_QUEUES.
+#ifndef SKR_PULL_QUEUES
 #define SKR_PULL_QUEUES 16u
+#endif
 #define SKR_PULL_STRIDE 256u
 
 struct RenderParams {
