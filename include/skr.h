@@ -84,12 +84,14 @@ int skr_scene_get_info(const skr_scene *scene, skr_scene_info *info);
  * (any pointer may be NULL).  Used by the loader parity tests. */
 int skr_scene_get_arrays(const skr_scene *scene, float *spheres, float *triangles, float *point_lights);
 /* The culling data the triangle walk of raytrace.h:171-186 runs on, as uploaded:
- * device_tris[n_triangles][12] = {v0, 0, v1-v0, 0, v2-v0, 0} in device (Morton) order; chunk_spheres[n_chunks][4]
- * = centre, radius^2 of every *chunk_size consecutive device triangles; above them a tree in depth-first order,
- * node_spheres[n_nodes][4] = centre, radius^2 and node_links[n_nodes][4] = {skip (index of the next node that is
- * not below this one), first chunk, chunk count (height-1 nodes only, else 0), height}.  level 0..2 selects the
- * radii built for ray directions up to 4 / 32 / 256 long (the launcher picks by camera and --fov).  Any pointer
- * may be NULL; the counts are returned first so the caller can size the arrays.  Used by the host-logic tests. */
+ * device_tris[n_triangles][12] = {v0, 0, v1-v0, 0, v2-v0, 0} in device (Morton) order; chunk_spheres[n_chunks][8]
+ * = {centre, R^2, axis / kappa, R_tight^2} of every *chunk_size consecutive device triangles (R_tight applies to
+ * rays with (d . axis / kappa)^2 >= d . d; axis = 0 and R_tight = R where there is none); above them a tree in
+ * depth-first order, node_spheres[n_nodes][8] likewise and node_links[n_nodes][4] = {skip (index of the next node
+ * that is not below this one), first chunk, chunk count (height-1 nodes only, else 0), height}.  level 0..2
+ * selects the R built for ray directions up to 4 / 32 / 256 long (the launcher picks by camera and --fov).  Any
+ * pointer may be NULL; the counts are returned first so the caller can size the arrays.  Used by the host-logic
+ * tests. */
 int skr_scene_get_culling(const skr_scene *scene, int32_t level, int32_t *chunk_size, int32_t *n_nodes, int32_t *n_chunks,
 						  float *device_tris, float *node_spheres, int32_t *node_links, float *chunk_spheres);
 

@@ -149,14 +149,14 @@ class Scene:
         return s, t, l
 
     def culling(self, level=0):
-        """(chunk_size, device_tris [n,3,4], node_spheres [nn,4], node_links [nn,4] int32, chunk_spheres [nc,4]) —
+        """(chunk_size, device_tris [n,3,4], node_spheres [nn,8], node_links [nn,4] int32, chunk_spheres [nc,8]) —
         include/skr.h skr_scene_get_culling."""
         cs, nn, nc = C.c_int32(), C.c_int32(), C.c_int32()
         _check(lib().skr_scene_get_culling(self.h, level, C.byref(cs), C.byref(nn), C.byref(nc), None, None, None, None), "skr_scene_get_culling")
         tris = np.zeros((self.info.n_triangles, 3, 4), np.float32)
-        sph = np.zeros((nn.value, 4), np.float32)
+        sph = np.zeros((nn.value, 8), np.float32)
         links = np.zeros((nn.value, 4), np.int32)
-        ch = np.zeros((nc.value, 4), np.float32)
+        ch = np.zeros((nc.value, 8), np.float32)
         _check(lib().skr_scene_get_culling(self.h, level, None, None, None, tris.ctypes.data, sph.ctypes.data, links.ctypes.data, ch.ctypes.data),
                "skr_scene_get_culling")
         return cs.value, tris, sph, links, ch

@@ -36,7 +36,7 @@ struct skr_renderer {
 	skr_scene_info info{};
 	float4 *d_blob = nullptr; // one allocation: geom | amb | kd | ks | lights | tris
 	size_t off_amb = 0, off_kd = 0, off_ks = 0, off_lights = 0, off_tris = 0, off_chunks = 0;
-	int n_chunks = 0, chunk_size = 0;
+	int n_chunks = 0, chunk_size = 0, cones = 0;
 	size_t chunk_stride = 0;
 	unsigned long long *d_counters = nullptr;
 	int lds_limit = 0;
@@ -96,6 +96,7 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	r->off_chunks = 4 * ns + nl2 + nt3;
 	r->chunk_size = scene->tri_chunk_size;
 	r->chunk_stride = scene->tri_chunk_stride;
+	r->cones = scene->tri_any_cone ? 1 : 0;
 	r->n_chunks = scene->info.n_triangles ? scene->tri_node_count : 0; // nodes of the chunk tree (two float4 each, + a pad node)
 	const size_t total = 4 * ns + nl2 + nt3 + nch;
 	std::vector<skr_f4> blob(total > 0 ? total : 1);
@@ -225,6 +226,7 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.tris = r->d_blob + r->off_tris;
 	p.tri_chunks = r->d_blob + r->off_chunks;
 	p.tri_chunk_size = r->chunk_size;
+	p.tri_cones = (r->cones && !getenv("SKR_NO_CONES")) ? 1 : 0;
 	{ // pick the tightest set of chunk spheres whose |d| bound covers this frame's camera rays (GI children stay below 4,
 	  // the smallest bound): primary directions are dir + u right + v up (main.cpp:154-155)
 		auto len3 = [](const float *v) { return std::sqrt((double) v[0] * v[0] + (double) v[1] * v[1] + (double) v[2] * v[2]); };

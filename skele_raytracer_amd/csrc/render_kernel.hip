@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void skr_render_kernel(const RenderParams p)
 	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	__syncthreads();
 
-	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size};
+	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
 
 	const int wave = tid >> 6, lane = tid & 63;
 	const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);

@@ -29,9 +29,10 @@ struct RenderParams {
 	// SoA scene in HBM (scene_host.h)
 	int32_t n_spheres, n_tris, n_lights;
 	const float4 *sph_geom, *sph_amb, *sph_kd, *sph_ks, *lights, *tris;
-	const float4 *tri_chunks; // the chunk tree of the triangle walk (scene_host.h): 2 float4 per node, depth-first, skip links
+	const float4 *tri_chunks; // the chunk tree of the triangle walk (scene_host.h): 3 float4 per node, depth-first, skip links, then 2 float4 per chunk
 	int32_t tri_chunk_size;
 	uint32_t gi_groups_per_slot, gi_group_round; // GI kernel group-size policy (set by skr_launch_queue)
+	int32_t tri_cones;        // some entry has a tight radius for non-grazing rays (else the cone test is compiled out of the walk)
 	int32_t n_tri_chunks;     // its node count; 0 = culling off (ray directions longer than the bounds were built for)
 	// utils.h:26-34 Options + scene.use_shadows
 	int32_t monte_carlo, num_path_traces, grid_size, max_depth, use_shadows;

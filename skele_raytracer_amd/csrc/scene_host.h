@@ -30,16 +30,18 @@ struct skr_scene {
 	std::vector<skr_f4> sph_ks;   // material.specular
 	std::vector<skr_f4> lights;   // [2*i] position, [2*i+1] colour
 	std::vector<skr_f4> tris;     // [3*i] v0, [3*i+1] v1-v0, [3*i+2] v2-v0 (utils.h:183-184 subtractions)
-	// the chunk tree of the triangle walk, depth-first with skip links, two float4 per node: {centre, radius^2}
-	// {skip, first triangle, triangle count, level} (ints), + one pad node.  Leaves hold tri_chunk_size consecutive
-	// triangles, every inner node SKR_TRI_SUPER children; a sphere is conservative: a line that
+	// the culling data of the triangle walk: a tree, depth-first with skip links, three float4 per node — {centre, R^2}
+	// {axis / kappa, R_tight^2} {skip, first chunk, chunk count, height} (ints) — + one pad node, then two float4 per
+	// chunk of tri_chunk_size consecutive triangles — {centre, R^2} {axis / kappa, R_tight^2} — + one pad entry.
+	// Every inner node has SKR_TRI_SUPER children; a sphere is conservative: a line that
 	// misses it cannot pass utils.h:181-213 for any triangle of the chunk (see finalize())
 	std::vector<skr_f4> tri_chunks; // SKR_CULL_LEVELS sets of them, one per bound on |d| (tri_chunks.h)
 	int tri_chunk_size = SKR_TRI_CHUNK_MIXED;
 
 	void finalize();
-	size_t tri_chunk_stride = 0; // float4 entries per |d| level: 2 per node + 2 of padding
+	size_t tri_chunk_stride = 0; // float4 entries per |d| level
 	int tri_node_count = 0;
+	bool tri_any_cone = false; // some chunk has a tight radius for non-grazing rays (scene_host.cpp)
 	void build_triangle_chunks();
 	void build_triangle_chunk_level(double d_max, std::vector<skr_f4> &out);
 };

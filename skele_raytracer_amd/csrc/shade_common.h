@@ -23,6 +23,7 @@ struct SceneView {
 	                      //      + a pad node, then one conservative sphere (centre, radius^2) per chunk of triangles
 	int nchunks;          // nodes in the tree; 0 = walk every triangle
 	int chunk;            // triangles per chunk sphere (tri_chunks.h)
+	int cones;            // some entry carries a tight radius for non-grazing rays
 };
 
 struct Counters {
@@ -101,66 +102,86 @@ SKR_DEV int closest_sphere(const SceneView &sv, const RayConst &r, float &tmin)
 	return best;
 }
 
+// The conservative line-sphere test of the culling data (scene_host.cpp build_triangle_chunks): false only where
+// no triangle below the entry can accept this lane's line.  A = {centre, R^2}; B = {axis / kappa, R_tight^2}: a ray
+// that is not grazing for the entry's (nearly coplanar) triangles, (d . axis / kappa)^2 >= d . d, is held to the
+// tight radius.  NaN anywhere => true.
+template <bool CONES>
+SKR_DEV bool line_touches(const RayConst &r, float dd, float4 A, float4 B)
+{
+	const f3 e = ld3(A) - r.o;
+	const f3 cr = cross3(e, r.d);
+	float R2 = A.w;
+	if constexpr(CONES)
+	{
+		const float gb = dot3(r.d, ld3(B));
+		R2 = (gb * gb >= dd) ? B.w : A.w;
+	}
+	return !(dot3(cr, cr) > R2 * dd); // |e x d|^2 <= R^2 |d|^2
+}
+
+// A line that misses a conservative sphere cannot pass the test for any triangle below it, so a node or chunk that
+// no lane's line touches is skipped whole.  The levels above the chunks are stored depth-first with skip links:
+// one wave-uniform index, no stack; both possible successors are fetched (scalar loads) while the sphere is tested.
+template <bool CONES>
+SKR_DEV bool tree_walk(const SceneView &sv, const RayConst &r, float tmin)
+{
+	bool hit = false;
+	const float dd = r.two_a * 0.5f; // dot(d, d)
+	int i = 0;
+	const float4 *chunk_ent = sv.chunks + 3 * (sv.nchunks + 1); // behind the nodes and their pad
+	float4 A = sv.chunks[0], B = sv.chunks[1], lk = sv.chunks[2];
+	while(i < sv.nchunks)
+	{
+		const int i_out = __float_as_int(lk.x);
+		// first child (or the next node after a height-1 node) and next sibling (padded past the end)
+		const float4 A_in = sv.chunks[3 * i + 3], B_in = sv.chunks[3 * i + 4], lk_in = sv.chunks[3 * i + 5];
+		const float4 A_out = sv.chunks[3 * i_out], B_out = sv.chunks[3 * i_out + 1], lk_out = sv.chunks[3 * i_out + 2];
+		const bool enter = __any(!hit && line_touches<CONES>(r, dd, A, B));
+		const int count = __float_as_int(lk.z);
+		if(enter && count > 0)
+		{ // height 1: its chunk entries are contiguous — tight loop, next entry prefetched
+			const int c0 = __float_as_int(lk.y), c1 = c0 + count;
+			float4 cA_next = chunk_ent[2 * c0], cB_next = chunk_ent[2 * c0 + 1];
+			for(int c = c0; c < c1; c++)
+			{
+				const float4 cA = cA_next, cB = cB_next;
+				cA_next = chunk_ent[2 * c + 2];
+				cB_next = chunk_ent[2 * c + 3];
+				const bool mine = !hit && line_touches<CONES>(r, dd, cA, cB);
+				if(__any(mine))
+				{
+					const int i0 = c * sv.chunk, i1 = (i0 + sv.chunk < sv.nt) ? i0 + sv.chunk : sv.nt;
+					float4 n0 = sv.tris[3 * i0], n1 = sv.tris[3 * i0 + 1], n2 = sv.tris[3 * i0 + 2];
+					for(int k = i0; k < i1; k++)
+					{
+						const f3 v0 = ld3(n0), e1 = ld3(n1), e2 = ld3(n2);
+						n0 = sv.tris[3 * k + 3];
+						n1 = sv.tris[3 * k + 4];
+						n2 = sv.tris[3 * k + 5];
+						float t;
+						if(mine && !hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
+					}
+				}
+			}
+			if(__all(hit)) break;
+		}
+		i = enter ? i + 1 : i_out;
+		A = enter ? A_in : A_out;
+		B = enter ? B_in : B_out;
+		lk = enter ? lk_in : lk_out;
+	}
+	return hit;
+}
+
 // raytrace.h:171-186.  The outcome is binary: once a triangle passes with
 // t < min_distance the sample is black (:221-224) whatever comes later, so a
 // lane stops testing at its first accepted triangle and the wave leaves the
 // loop when every active lane has.
 SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float tmin)
 {
+	if(sv.nchunks > 0) return sv.cones ? tree_walk<true>(sv, r, tmin) : tree_walk<false>(sv, r, tmin);
 	bool hit = false;
-	if(sv.nchunks > 0)
-	{ // A line that misses a conservative sphere cannot pass the test for any triangle below it (scene_host.cpp
-	  // build_triangle_chunks), so a node or chunk that no lane's line touches is skipped whole.  The levels above
-	  // the chunks are stored depth-first with skip links: one wave-uniform index, no stack; both possible
-	  // successors are fetched (scalar loads) while the sphere is tested.
-		const float dd = r.two_a * 0.5f; // dot(d, d)
-		int i = 0;
-		const float4 *chunk_sph = sv.chunks + 2 * (sv.nchunks + 1); // behind the nodes and their pad
-		float4 sp = sv.chunks[0], lk = sv.chunks[1];
-		while(i < sv.nchunks)
-		{
-			const int i_out = __float_as_int(lk.x);
-			const float4 sp_in = sv.chunks[2 * i + 2], lk_in = sv.chunks[2 * i + 3];       // first child, or the next node after a leaf
-			const float4 sp_out = sv.chunks[2 * i_out], lk_out = sv.chunks[2 * i_out + 1]; // next sibling (padded past the end)
-			const f3 e = ld3(sp) - r.o;
-			const f3 cr = cross3(e, r.d);
-			const bool maybe = !hit && !(dot3(cr, cr) > sp.w * dd); // |e x d|^2 <= R^2 |d|^2; NaN => enter the node
-			const bool enter = __any(maybe);
-			const int count = __float_as_int(lk.z);
-			if(enter && count > 0)
-			{ // height 1: its chunk spheres are contiguous — tight loop, next sphere prefetched
-				const int c0 = __float_as_int(lk.y), c1 = c0 + count;
-				float4 c_next = chunk_sph[c0];
-				for(int c = c0; c < c1; c++)
-				{
-					const float4 ch = c_next;
-					c_next = chunk_sph[c + 1];
-					const f3 ec = ld3(ch) - r.o;
-					const f3 crc = cross3(ec, r.d);
-					const bool mine = !hit && !(dot3(crc, crc) > ch.w * dd);
-					if(__any(mine))
-					{
-						const int i0 = c * sv.chunk, i1 = (i0 + sv.chunk < sv.nt) ? i0 + sv.chunk : sv.nt;
-						float4 n0 = sv.tris[3 * i0], n1 = sv.tris[3 * i0 + 1], n2 = sv.tris[3 * i0 + 2];
-						for(int k = i0; k < i1; k++)
-						{
-							const f3 v0 = ld3(n0), e1 = ld3(n1), e2 = ld3(n2);
-							n0 = sv.tris[3 * k + 3];
-							n1 = sv.tris[3 * k + 4];
-							n2 = sv.tris[3 * k + 5];
-							float t;
-							if(mine && !hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
-						}
-					}
-				}
-				if(__all(hit)) break;
-			}
-			i = enter ? i + 1 : i_out;
-			sp = enter ? sp_in : sp_out;
-			lk = enter ? lk_in : lk_out;
-		}
-		return hit;
-	}
 	// wave-uniform addresses => scalar loads; triangle i+1 is fetched while i is tested
 	// (tris[] carries one pad triangle so the prefetch needs no bounds test)
 	float4 n0 = sv.tris[0], n1 = sv.tris[1], n2 = sv.tris[2];

@@ -2,12 +2,17 @@
 // build_triangle_chunks) and the device walk (shade_common.h any_triangle_closer).
 #pragma once
 
-/* Consecutive (Morton-ordered) triangles per first-level sphere, chosen per scene by skr_scene::finalize():
- * scenes without spheres only ever trace camera rays, whose 8x8-pixel waves are coherent and gain from small
- * chunks (dragon 1080p: 2.14 / 1.80 / 1.53 ms at 32 / 16 / 8); scenes with spheres also trace GI children whose
- * waves touch most chunks anyway, and pay for every extra sphere test (test.scn 2.77 / 2.87 / 3.04 ms). */
-#define SKR_TRI_CHUNK_COHERENT 8
-#define SKR_TRI_CHUNK_MIXED 32
+/* Consecutive (Morton-ordered) triangles per chunk sphere, chosen per scene by skr_scene::finalize(): scenes
+ * without spheres only ever trace camera rays, whose 8x8-pixel waves are coherent and gain from small chunks
+ * (dragon 1080p under the tree walk: 1.45 / 1.35 / 1.22 / 1.19 ms at 8 / 6 / 4 / 2); scenes with spheres also trace
+ * GI children whose waves touch many chunks and pay for every extra sphere test (test.scn: 1.84 / 1.58 / 1.56 /
+ * 1.54 / 1.61 ms at 4 / 8 / 12 / 16 / 32).  SKR_TRI_CHUNK in the environment overrides both (tuning runs). */
+#ifndef SKR_TRI_CHUNK_COHERENT
+#define SKR_TRI_CHUNK_COHERENT 4
+#endif
+#ifndef SKR_TRI_CHUNK_MIXED
+#define SKR_TRI_CHUNK_MIXED 16
+#endif
 #ifndef SKR_TRI_SUPER
 #define SKR_TRI_SUPER 8 /* children per node of the tree above the chunk spheres */
 #endif

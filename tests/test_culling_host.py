@@ -40,12 +40,18 @@ def triangle_accepts(o, d, v0, e1, e2):
     return ok
 
 
-def sphere_culls(o, d, sph):
-    """shade_common.h: skip iff dot(cr,cr) > R^2 * dot(d,d), cr = cross(centre - o, d); NaN never culls."""
+def sphere_culls(o, d, ent, cones=True):
+    """shade_common.h line_touches, negated: skip iff dot(cr,cr) > R2 * dot(d,d), cr = cross(centre - o, d), with
+    R2 = R_tight^2 for rays with (d . axis/kappa)^2 >= d . d and R^2 otherwise; NaN never culls."""
     with np.errstate(all="ignore"):
-        e = sph[..., :3] - o
+        e = ent[..., :3] - o
         cr = _cross(e, d)
-        return _dot(cr, cr) > sph[..., 3] * _dot(d, d)
+        dd = _dot(d, d)
+        R2 = ent[..., 3]
+        if cones:
+            gb = _dot(d, ent[..., 4:7])
+            R2 = np.where(gb * gb >= dd, ent[..., 7], ent[..., 3])
+        return _dot(cr, cr) > R2 * dd
 
 
 def _scene(name):
@@ -83,7 +89,7 @@ def test_device_triangles_are_a_permutation_of_the_file_triangles(name):
     assert np.all(tris[:, :, 3] == 0)
     key = lambda a: a[np.lexsort(a.T[::-1])]
     assert np.array_equal(key(want), key(got))
-    assert cs == (8 if sc.info.n_spheres == 0 else 32)
+    assert cs == (4 if sc.info.n_spheres == 0 else 16)
 
 
 @pytest.mark.parametrize("name", ["dragon.scn", "test.scn", "spheres1.scn"])
@@ -121,13 +127,18 @@ def test_spheres_contain_their_accept_regions_and_children(name):
     dist = np.linalg.norm(corners - c[:, None, :3], axis=2).max(axis=1)
     finite = np.isfinite(c[:, 3])
     assert np.all(dist[finite] < np.sqrt(c[finite, 3])), "an accept region sticks out of its chunk sphere"
+    assert np.all(dist < np.sqrt(c[:, 7])) and np.all(c[:, 7] <= c[:, 3]), "... or out of its tight sphere"
 
     def inside(child_sph, parent_sph, what):
-        both = np.isfinite(parent_sph[:, 3])
-        assert np.all(np.isfinite(child_sph[both, 3])), "an unbounded %s under a bounded node" % what
-        reach = np.linalg.norm(child_sph[both, :3].astype(np.float64) - parent_sph[both, :3].astype(np.float64), axis=1) \
-            + np.sqrt(child_sph[both, 3].astype(np.float64))
-        assert np.all(reach < np.sqrt(parent_sph[both, 3].astype(np.float64))), "a %s sticks out of its node" % what
+        for col in (3, 7):  # the general radii, and the tight ones where the parent has a cone
+            both = np.isfinite(parent_sph[:, col])
+            if col == 7:
+                both &= np.any(parent_sph[:, 4:7] != 0, axis=1)
+                assert np.all(np.any(child_sph[both, 4:7] != 0, axis=1)), "a %s without a cone under a node with one" % what
+            assert np.all(np.isfinite(child_sph[both, col])), "an unbounded %s under a bounded node" % what
+            reach = np.linalg.norm(child_sph[both, :3].astype(np.float64) - parent_sph[both, :3].astype(np.float64), axis=1) \
+                + np.sqrt(child_sph[both, col].astype(np.float64))
+            assert np.all(reach < np.sqrt(parent_sph[both, col].astype(np.float64))), "a %s sticks out of its node" % what
 
     inside(ch, sph[node_of_chunk], "chunk")
     if sph.shape[0] > 1:
@@ -170,8 +181,23 @@ def _border_rays(rng, sc, tris, n, level):
         on_sphere = sph[j, :3].astype(np.float64) + dirn * np.abs(sph[j, 3:4].astype(np.float64))
         from_cam = rng.random(n) < 0.5
         o = np.where(from_cam[:, None], o, on_sphere)
+    # a third of the rays graze their triangle: direction in its plane plus 1e-6 .. 1e-2 of the normal, from a point
+    # no farther than the scene's ray origins (the bounds only use the distance) — this is where |det| sits near
+    # 1e-5, the reference's u, v are noise and the cone test must fall back to the general radius
+    m = np.cross(e1, e2)
+    area2 = np.linalg.norm(m, axis=1, keepdims=True)
+    nrm = m / np.where(area2 > 0, area2, 1)
+    inplane = np.cross(nrm, rng.normal(size=(n, 3)))
+    inplane /= np.maximum(np.linalg.norm(inplane, axis=1, keepdims=True), 1e-300)
+    sinphi = (10.0 ** rng.uniform(-6, -2, (n, 1))) * rng.choice([-1.0, 1.0], (n, 1))
+    graze_d = inplane * np.sqrt(1 - sinphi ** 2) + nrm * sinphi
+    reach = np.minimum(np.linalg.norm(P - cam[None], axis=1, keepdims=True), 15.0)
+    graze_o = P - graze_d * rng.uniform(0.05, 1.0, (n, 1)) * reach
+    graze = (rng.random(n) < 0.33) & (area2[:, 0] > 0)
+    o = np.where(graze[:, None], graze_o, o)
     d = P - o
     ln = np.linalg.norm(d, axis=1, keepdims=True)
+    from_cam = from_cam | graze
     longest = np.where(from_cam, 0.98 * BOUNDS[level], 3.0)[:, None]
     scale = np.where(rng.random((n, 1)) < 0.4, 1.0, 10.0 ** (rng.random((n, 1)) * np.log10(longest / 0.5)) * 0.5)
     d = d / ln * scale
@@ -218,8 +244,11 @@ def test_no_accepted_pair_is_hidden_by_its_spheres(tmp_path, name, level):
     culled = sphere_culls(o, d, ch[other]).mean()
     if name == "test.scn":
         # unit-sized triangles 30-40 units from the ray origins: at grazing incidence the reference's binary32 u, v
-        # are off by more than an edge length, no bounded sphere is valid, and the walk stays brute force
-        assert not np.isfinite(sph[:, 3]).any() and not np.isfinite(ch[:, 3]).any() and culled == 0
+        # are off by more than an edge length and no general radius is finite — but the wall is planar, so every
+        # entry has a cone and a finite tight radius for the rays that are not grazing it
+        assert not np.isfinite(sph[:, 3]).any() and not np.isfinite(ch[:, 3]).any()
+        assert np.isfinite(ch[:, 7]).all() and np.isfinite(sph[:, 7]).all() and culled > 0.5
+        assert sphere_culls(o, d, ch[other], cones=False).sum() == 0
     elif not (name == "soup" and level == 2):  # at |d| <= 256 the soup's slack outgrows its chunks: mostly unbounded
         assert culled > 0.5, "the spheres must actually cull (%.2f)" % culled
 
@@ -230,5 +259,9 @@ def test_levels_nest():
     for which in (2, 4):  # node spheres, chunk spheres
         r = [sc.culling(level)[which][:, 3] for level in range(3)]
         assert np.all(r[0] <= r[1]) and np.all(r[1] <= r[2]) and np.any(r[0] < r[2])
+        tight = [sc.culling(level)[which][:, 4:8] for level in range(3)]
+        both = np.any(tight[0][:, :3] != 0, axis=1) & np.any(tight[2][:, :3] != 0, axis=1)
+        assert np.array_equal(tight[0][both], tight[2][both])  # cone and tight radius do not depend on the bound on |d|
+        # (an entry drops its cone at the levels where the general radius is already the smaller one)
     links = [sc.culling(level)[3] for level in range(3)]
     assert np.array_equal(links[0], links[1]) and np.array_equal(links[1], links[2])  # one topology, three sets of radii

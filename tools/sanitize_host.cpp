@@ -19,7 +19,7 @@ int main(int argc, char **argv)
 		{
 			int32_t cs = 0, nn = 0, nc = 0;
 			skr_scene_get_culling(sc, level, &cs, &nn, &nc, nullptr, nullptr, nullptr, nullptr);
-			std::vector<float> dt((size_t) info.n_triangles * 12 + 1), ns((size_t) nn * 4 + 1), ch((size_t) nc * 4 + 1);
+			std::vector<float> dt((size_t) info.n_triangles * 12 + 1), ns((size_t) nn * 8 + 1), ch((size_t) nc * 8 + 1);
 			std::vector<int32_t> nl((size_t) nn * 4 + 1);
 			skr_scene_get_culling(sc, level, nullptr, nullptr, nullptr, dt.data(), ns.data(), nl.data(), ch.data());
 		}
