@@ -414,3 +414,51 @@ def test_large_mesh_walk_scales_and_stays_exact(gpu, oracle, tmp_path, monkeypat
     assert black > 0.05 * w * h, "the mesh must cover a good part of the frame (%d black pixels)" % black
     print("\n%d triangles %dx%d: tree walk %.2f ms, brute force %.1f ms" % (nt, w, h, t_tree * 1e3, t_brute * 1e3))
     assert t_tree * 20 < t_brute
+
+
+def _write_grazing_floor(path, with_spheres):
+    """A tessellated strip of floor (4 x 24 unit quads) seen through a narrow lens from a camera 0.01 above its plane:
+    camera rays meet it between 0.02 rad and 0.0004 rad of grazing, across the kappa = 1e-3 of the culling data's cone
+    test — where it has to hand over to the general radius."""
+    lines = ["camera 0 0.01 -6 0 0 1 0 1 0 30", "background .2 .3 .4", "ambient_light .3 .3 .3"]
+    if with_spheres:
+        lines += ["material .6 .6 .6 .7 .7 .7 .2 .2 .2 8 0 0 0 1", "sphere -0.4 -0.9 3 1.0", "sphere 0.5 -0.75 9 0.8", "point_light 30 30 30 0 9 1"]
+    nx, nz = 4, 24
+    for i in range(nx + 1):
+        for j in range(nz + 1):
+            lines.append("vertex %g 0 %g" % (i - nx / 2.0, j - 5.5))
+    idx = lambda i, j: i * (nz + 1) + j
+    for i in range(nx):
+        for j in range(nz):
+            lines.append("triangle %d %d %d" % (idx(i, j), idx(i + 1, j), idx(i, j + 1)))
+            lines.append("triangle %d %d %d" % (idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)))
+    open(path, "w").write("\n".join(lines) + "\n")
+
+
+@pytest.mark.parametrize("with_spheres,kw", [(False, dict(fov=4.0)), (True, dict(fov=6.0, gillum=4, depth=2, shadow=True, seed=21)), (False, dict(jsample=2, fov=3.0, seed=22))],
+                         ids=["camera_rays", "gi", "aa_fov3"])
+def test_grazing_floor_cones_change_nothing(gpu, oracle, tmp_path, monkeypatch, with_spheres, kw):
+    scn = str(tmp_path / "floor.scn")
+    _write_grazing_floor(scn, with_spheres)
+    w, h = 160, 90
+    sc = skr.parse_scene(scn)
+    ch = sc.culling(0)[4]
+    assert np.any(ch[:, 4:7] != 0, axis=1).mean() > 0.9, "the floor's chunks must carry cones"
+    r = skr.Renderer(sc)
+    opt = skr.Options(w, h, **kw)
+    outs = []
+    for env in (None, "SKR_NO_CONES", "SKR_NO_CULL"):
+        monkeypatch.delenv("SKR_NO_CONES", raising=False)
+        monkeypatch.delenv("SKR_NO_CULL", raising=False)
+        if env:
+            monkeypatch.setenv(env, "1")
+        rgb, rgbf = r.render(opt, want_float=True)
+        gpu.cuda.synchronize()
+        outs.append((rgb.cpu().numpy(), rgbf.cpu().numpy()))
+    monkeypatch.delenv("SKR_NO_CULL", raising=False)
+    for rgb, rgbf in outs[1:]:
+        assert np.array_equal(rgb, outs[0][0]) and np.array_equal(rgbf.view(np.uint32), outs[0][1].view(np.uint32))
+    o_rgb, o_f, _ = oracle.render(scn, w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, **kw)
+    compare(outs[0][0], outs[0][1], o_rgb, o_f, "grazing floor")
+    black = int((o_rgb.reshape(-1, 3).sum(axis=1) == 0).sum())
+    assert 0.02 * w * h < black < 0.95 * w * h, "floor and sky must both be visible (%d black pixels)" % black
