@@ -10,6 +10,7 @@ import pytest
 
 import skele_raytracer_amd as skr
 from conftest import scene_path
+from scenegen import write_random_mesh_scene
 
 f32 = np.float32
 
@@ -265,3 +266,28 @@ def test_levels_nest():
         # (an entry drops its cone at the levels where the general radius is already the smaller one)
     links = [sc.culling(level)[3] for level in range(3)]
     assert np.array_equal(links[0], links[1]) and np.array_equal(links[1], links[2])  # one topology, three sets of radii
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_mesh_scenes_hide_no_accepted_pair(tmp_path, seed):
+    """The scenes of tests/test_gpu_parity.py::test_random_meshes_match_oracle (planar patches of any size and
+    orientation, slivers, degenerate triangles, spheres): all three |d| levels, cones included."""
+    path = str(tmp_path / "mesh.scn")
+    write_random_mesh_scene(path, np.random.default_rng(1000 + seed))
+    sc = skr.parse_scene(path)
+    for level in range(3):
+        cs, tris, sph, links, ch = sc.culling(level)
+        parent, node_of_chunk = tree_parents(links)
+        n = 60000
+        k, o, d = _border_rays(np.random.default_rng(seed * 7 + level), sc, tris, n, level)
+        t = tris[k]
+        acc = triangle_accepts(o, d, t[:, 0, :3], t[:, 1, :3], t[:, 2, :3])
+        assert acc.sum() > 0.05 * n
+        chunk = k // cs
+        hidden = acc & sphere_culls(o, d, ch[chunk])
+        node = node_of_chunk[chunk]
+        while np.any(node >= 0):
+            live = node >= 0
+            hidden[live] |= acc[live] & sphere_culls(o[live], d[live], sph[node[live]])
+            node = np.where(live, parent[np.maximum(node, 0)], -1)
+        assert not hidden.any(), "level %d: %d accepted (ray, triangle) pairs would have been culled" % (level, hidden.sum())

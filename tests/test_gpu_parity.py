@@ -9,6 +9,7 @@ import pytest
 import skele_raytracer_amd as skr
 from skele_raytracer_amd import binding
 from conftest import args_to_kwargs, manifest, read_golden_ppm, scene_path
+from scenegen import write_random_mesh_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -462,3 +463,31 @@ def test_grazing_floor_cones_change_nothing(gpu, oracle, tmp_path, monkeypatch, 
     compare(outs[0][0], outs[0][1], o_rgb, o_f, "grazing floor")
     black = int((o_rgb.reshape(-1, 3).sum(axis=1) == 0).sum())
     assert 0.02 * w * h < black < 0.95 * w * h, "floor and sky must both be visible (%d black pixels)" % black
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_meshes_match_oracle(gpu, oracle, tmp_path, monkeypatch, seed):
+    """Random planar patches + triangle soup under random options: the culled walk (cones where they exist) against the
+    brute-force oracle, and against the GPU's own brute-force walk."""
+    rng = np.random.default_rng(1000 + seed)
+    scn = str(tmp_path / "mesh.scn")
+    write_random_mesh_scene(scn, rng)
+    kw = dict(fov=float(rng.choice([20, 45, 60, 100, 140])), seed=int(rng.integers(1, 1 << 30)))
+    if rng.random() < 0.6:
+        kw.update(gillum=int(rng.choice([2, 3, 5])), depth=int(rng.choice([2, 3])))
+    if rng.random() < 0.4:
+        kw.update(jsample=2)
+    if rng.random() < 0.5:
+        kw.update(shadow=True)
+    w, h = 64, 40
+    r = skr.Renderer(skr.parse_scene(scn))
+    monkeypatch.delenv("SKR_NO_CULL", raising=False)
+    rgb, rgbf = r.render(skr.Options(w, h, **kw), want_float=True)
+    monkeypatch.setenv("SKR_NO_CULL", "1")
+    rgb2, rgbf2 = r.render(skr.Options(w, h, **kw), want_float=True)
+    monkeypatch.delenv("SKR_NO_CULL", raising=False)
+    gpu.cuda.synchronize()
+    a, af = rgb.cpu().numpy(), rgbf.cpu().numpy()
+    assert np.array_equal(a, rgb2.cpu().numpy()) and np.array_equal(af.view(np.uint32), rgbf2.cpu().numpy().view(np.uint32))
+    o_rgb, o_f, st = oracle.render(scn, w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, **kw)
+    compare(a, af, o_rgb, o_f, "random mesh %d %s" % (seed, kw))
