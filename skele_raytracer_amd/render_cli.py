@@ -1,0 +1,126 @@
+"""`raytracer` for one node of MI355Xs: the reference's command line (README.md:24-34, main.cpp:246-391), one process
+per GPU.
+
+    python -m skele_raytracer_amd.render_cli --path S.scn --output O.ppm [--width i] [--height i] [--fov f]
+           [--gillum n] [--jsample g] [--depth d] [--parallel true|false] [--shadow] [--seed N] [--tile-rows r]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+           -m skele_raytracer_amd.render_cli --path spheres2.scn --output out.ppm --width 3840 --height 2160 \\
+           --gillum 64 --jsample 5 --shadow            # BASELINE config 5
+
+The framebuffer is cut into interleaved row tiles (tile t -> rank t mod G), every rank renders its tiles with one
+`skr_render_tiles` launch sequence, ONE RCCL all-gather brings the u8 tiles to every rank and rank 0 de-interleaves
+and writes the PPM (distributed.py).  The image does not depend on G: random numbers are keyed by the global pixel.
+Flags are matched like the reference does — by `strcmp` anywhere in argv, unknown tokens ignored — and usage errors
+print the reference's messages and exit with status 0 (main.cpp:381-391).  There is no CPU path.
+"""
+import os
+import sys
+import time
+
+
+def _parse(argv):
+    """main.cpp:246-379: flags anywhere, the value is the next token; bad numbers are usage errors."""
+    opt = dict(path=None, output=None, width=1920, height=1080, fov=60.0, gillum=None, jsample=None, depth=3, shadow=False, seed=1, tile_rows=8)
+
+    def value(i, kind, what):
+        if i + 1 >= len(argv):
+            raise ValueError(what)
+        try:
+            return kind(argv[i + 1])
+        except ValueError:
+            raise ValueError(what)
+
+    for i, a in enumerate(argv):
+        if a == "--path":
+            opt["path"] = value(i, str, "path must be passed after --path")
+        elif a == "--output":
+            opt["output"] = value(i, str, "output path must be passed after --output")
+        elif a == "--width":
+            opt["width"] = value(i, int, "width takes an int after flag for the width")
+        elif a == "--height":
+            opt["height"] = value(i, int, "height takes an int after flag for the width")
+        elif a == "--fov":
+            opt["fov"] = value(i, float, "fov takes a float (degrees) after flag for the field of view")
+        elif a == "--gillum":
+            try:
+                opt["gillum"] = value(i, int, "")
+            except ValueError:  # main.cpp:258 warns and goes on
+                print("gillum takes an int after flag for the number of paths traced", file=sys.stderr)
+        elif a == "--jsample":
+            opt["jsample"] = value(i, int, "jsample takes an int after flag for the supersampling grid size")
+        elif a == "--depth":
+            opt["depth"] = value(i, int, "depth takes a positive int after flag for the max depth")
+        elif a == "--shadow":
+            opt["shadow"] = True
+        elif a == "--seed":
+            opt["seed"] = value(i, int, "seed takes an int")
+        elif a == "--tile-rows":
+            opt["tile_rows"] = value(i, int, "tile-rows takes a positive int")
+    if opt["width"] <= 0 or opt["height"] <= 0:
+        raise ValueError("width/height take a positive int")
+    if opt["depth"] <= 0:
+        raise ValueError("depth takes a positive int after flag for the max depth")
+    if opt["tile_rows"] <= 0:
+        raise ValueError("tile-rows takes a positive int")
+    if opt["path"] is None:
+        raise ValueError("no scene file was passed. Pass with --path path_to_scn")
+    if opt["output"] is None:
+        raise ValueError("no output destination was passed. Pass with --output destination_path.ppm")
+    return opt
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    try:
+        o = _parse(argv)
+    except ValueError as e:
+        print(str(e), file=sys.stderr)
+        return 0  # the reference's usage errors leave with status 0
+    import torch
+    import torch.distributed as dist
+    import skele_raytracer_amd as skr
+    from .distributed import FrameSharder
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise skr.SkrError("no MI355X visible: the renderer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+    try:
+        scene = skr.parse_scene(o["path"])
+    except skr.SkrError as e:
+        if rank == 0:
+            print(str(e))  # scene.cpp:24: "Can't open file" on stdout, exit(0)
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+    r = skr.Renderer(scene, local_rank)
+    kw = dict(fov=o["fov"], depth=o["depth"], shadow=o["shadow"], seed=o["seed"])
+    if o["gillum"] is not None:
+        kw["gillum"] = o["gillum"]
+    if o["jsample"] is not None:
+        kw["jsample"] = o["jsample"]
+    opt = skr.Options(o["width"], o["height"], **kw)
+    sharder = FrameSharder(o["width"], o["height"], o["tile_rows"], rank, world, dev)
+    stream = torch.cuda.current_stream(dev)
+    t0 = time.perf_counter()
+    frame = sharder.step(lambda buf: r.render_tiles_into(opt, o["tile_rows"], rank, world, buf.data_ptr(), None, stream.cuda_stream))
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        skr.write_ppm(o["output"], frame.cpu().numpy())
+        print("***\nWROTE TO PPM\n***")  # main.cpp:213
+        print("%d GPU(s), %dx%d, %.3f ms (render + gather), kernel %s" % (world, o["width"], o["height"], dt * 1e3, r.kernel_variant()), file=sys.stderr)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

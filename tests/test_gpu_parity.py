@@ -491,3 +491,28 @@ def test_random_meshes_match_oracle(gpu, oracle, tmp_path, monkeypatch, seed):
     assert np.array_equal(a, rgb2.cpu().numpy()) and np.array_equal(af.view(np.uint32), rgbf2.cpu().numpy().view(np.uint32))
     o_rgb, o_f, st = oracle.render(scn, w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, **kw)
     compare(a, af, o_rgb, o_f, "random mesh %d %s" % (seed, kw))
+
+
+def test_distributed_cli_writes_the_same_ppm(gpu, tmp_path):
+    """python -m skele_raytracer_amd.render_cli (one process per GPU, here world size 1 directly and under
+    torch.distributed.run) must write the PPM the C++ raytracer writes, and keep the reference's usage behaviour."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "bin", "raytracer")
+    args = ["--path", scene_path("spheres2.scn"), "--width", "200", "--height", "120", "--gillum", "4", "--shadow", "--seed", "5", "--bogus", "x"]
+    want = str(tmp_path / "cpp.ppm")
+    subprocess.run([exe] + args + ["--output", want, "--quiet"], check=True, capture_output=True, timeout=120)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    got = str(tmp_path / "py.ppm")
+    res = subprocess.run([sys.executable, "-m", "skele_raytracer_amd.render_cli"] + args + ["--output", got], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode == 0 and "WROTE TO PPM" in res.stdout, res.stderr
+    assert open(got, "rb").read() == open(want, "rb").read()
+    got2 = str(tmp_path / "py2.ppm")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29577",
+                          "-m", "skele_raytracer_amd.render_cli"] + args + ["--output", got2, "--tile-rows", "16"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr
+    assert open(got2, "rb").read() == open(want, "rb").read()
+    res = subprocess.run([sys.executable, "-m", "skele_raytracer_amd.render_cli", "--output", got], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert res.returncode == 0 and "no scene file was passed" in res.stderr
