@@ -97,7 +97,7 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	r->chunk_size = scene->tri_chunk_size;
 	r->chunk_stride = scene->tri_chunk_stride;
 	r->cones = scene->tri_any_cone ? 1 : 0;
-	r->n_chunks = scene->info.n_triangles ? scene->tri_node_count : 0; // nodes of the chunk tree (two float4 each, + a pad node)
+	r->n_chunks = scene->info.n_triangles ? scene->tri_node_count : 0; // nodes of the chunk tree (scene_host.h)
 	const size_t total = 4 * ns + nl2 + nt3 + nch;
 	std::vector<skr_f4> blob(total > 0 ? total : 1);
 	if(ns)
