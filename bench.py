@@ -80,11 +80,19 @@ def main():
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path)"
+    # SKR_REHEARSE_GLOO=1: every rank on GPU 0 and the collectives over gloo — how the N > 1 path (partition, gather,
+    # de-interleave, rank reductions) is rehearsed on a one-GPU box (tests/test_gpu_parity.py); never a measurement
+    rehearsal = world > 1 and os.environ.get("SKR_REHEARSE_GLOO") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     from skele_raytracer_amd.distributed import FrameSharder
 
@@ -176,7 +184,7 @@ def main():
                        "rays_per_frame": rays_per_frame, "nominal_rays": skr.radiance_ray_count(opt),
                        "nominal_mrays_per_s": skr.radiance_ray_count(opt) * args.steps / dt / 1e6,
                        "shadow_rays_per_frame": shadow / args.steps, "partition": "interleaved %d-row tiles, rank = tile %% %d" % (TILE_ROWS, world),
-                       "gather": "RCCL all-gather of the u8 tile buffers, rank 0 de-interleaves" if world > 1 else "none (1 GPU)",
+                       "gather": ("REHEARSAL on one GPU over gloo - not a measurement" if rehearsal else "RCCL all-gather of the u8 tile buffers, rank 0 de-interleaves") if world > 1 else "none (1 GPU)",
                        "kernel": r.kernel_variant(), "seed": KW["seed"]},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,

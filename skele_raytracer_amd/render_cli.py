@@ -86,11 +86,18 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise skr.SkrError("no MI355X visible: the renderer has no CPU path")
+    # SKR_REHEARSE_GLOO=1: every rank on GPU 0, collectives over gloo (rehearsal of the N > 1 path on a one-GPU box)
+    rehearsal = world > 1 and os.environ.get("SKR_REHEARSE_GLOO") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
     try:
         scene = skr.parse_scene(o["path"])
     except skr.SkrError as e:

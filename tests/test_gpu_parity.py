@@ -516,3 +516,32 @@ def test_distributed_cli_writes_the_same_ppm(gpu, tmp_path):
     assert open(got2, "rb").read() == open(want, "rb").read()
     res = subprocess.run([sys.executable, "-m", "skele_raytracer_amd.render_cli", "--output", got], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
     assert res.returncode == 0 and "no scene file was passed" in res.stderr
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_paths_rehearsed_on_one_gpu(gpu, tmp_path, world):
+    """bench.py and render_cli under torch.distributed.run with `world` ranks, all on GPU 0 with gloo carrying the
+    collectives (SKR_REHEARSE_GLOO=1): partition, gather, de-interleave and the rank reductions of the N > 1 path run
+    on real kernels — the PPM must equal the single-process one and the ray count must not depend on the world size."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, PYTHONPATH=ROOT, SKR_REHEARSE_GLOO="1")
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+              "--master-port", str(29620 + world)]
+    args = ["--path", scene_path("spheres2.scn"), "--width", "333", "--height", "187", "--gillum", "4", "--jsample", "2", "--shadow", "--seed", "5"]
+    want = str(tmp_path / "one.ppm")
+    subprocess.run([os.path.join(ROOT, "bin", "raytracer")] + args + ["--output", want, "--quiet"], check=True, capture_output=True, timeout=120)
+    got = str(tmp_path / "many.ppm")
+    res = subprocess.run(launch + ["-m", "skele_raytracer_amd.render_cli"] + args + ["--output", got], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert open(got, "rb").read() == open(want, "rb").read()
+    res = subprocess.run(launch + [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == world and out["steps"] == 3 and out["scaling"] == "strong" and "REHEARSAL" in out["config"]["gather"]
+    assert out["config"]["rays_per_frame"] == 72909584.0 and out["config"]["shadow_rays_per_frame"] == 34474374.0
+    assert "cpu_baseline" not in out and out["roofline"]["kernel_ms"] > 0
