@@ -1308,10 +1308,8 @@ static hipError_t launch_gi(const RenderParams &p, size_t lds, hipStream_t strea
 hipError_t skr_launch_queue(const RenderParams &p_in, hipStream_t stream, const SkrTimingHook *hook)
 {
 	RenderParams p = p_in;
-	p.gi_groups_per_slot = 8u;
+	p.gi_groups_per_slot = 8u; // 2..8 groups per wave slot and multiples of 4 or 8 measured flat on 1/8..1/32 frames
 	p.gi_group_round = 8u;
-	if(const char *e = getenv("SKR_GPS")) p.gi_groups_per_slot = (uint32_t) atoi(e) > 0 ? (uint32_t) atoi(e) : 8u;
-	if(const char *e = getenv("SKR_GROUND")) p.gi_group_round = (uint32_t) atoi(e) == 4u ? 4u : 8u;
 	const int nsamp = p.grid_size > 0 ? p.grid_size * p.grid_size : 1;
 	const size_t lds1 = ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 32;
 	const bool occ3 = wave_occ_for(p) == 3;
