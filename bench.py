@@ -32,6 +32,29 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
 
 
+def reference_sample(orc):
+    """The reference's own shade()/parseScene() (oracle/_ref/ref_render: its sources compiled in place in the build
+    container, serial entry — the only one that can run this configuration) on ONE core, on a 320x180 sample of the
+    headline configuration; the ray count comes from the oracle's replay mode, which is bit-identical to it."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_render")
+    if not os.path.exists(exe):
+        return None
+    import subprocess
+    import tempfile
+    w, h = 320, 180
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            t0 = time.perf_counter()
+            subprocess.run([exe, "--path", SCENE, "--output", os.path.join(tmp, "ref.ppm"), "--width", str(w), "--height", str(h), "--gillum", str(KW["gillum"]),
+                            "--shadow", "--depth", str(KW["depth"]), "--seed", "1"], check=True, capture_output=True, timeout=120, cwd=tmp)
+            dt = time.perf_counter() - t0
+        _, _, st = orc.render(SCENE, w, h, rng=orc.RNG_GLIBC_REPLAY, math=orc.MATH_LIBM, gillum=KW["gillum"], shadow=KW["shadow"], depth=KW["depth"], seed=1)
+        return {"value": int(st[0]) / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
+                "sample": "oracle/_ref/ref_render %dx%d --gillum %d --shadow: %d radiance rays in %.2f s (process start and scene parse included)" % (w, h, KW["gillum"], int(st[0]), dt)}
+    except Exception as e:  # the checker binary is optional; the port above is the baseline
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
 def cpu_baseline():
     """The oracle (CPU restatement, counter RNG, OpenMP over (row, 32-pixel span) items) timed on this
     box's host cores on the same workload: whole frames, repeated until >= 8 s of wall time."""
@@ -54,7 +77,8 @@ def cpu_baseline():
             model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "unknown")
     except OSError:
         pass
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "cpu_model": model,
+    reference = reference_sample(orc)
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "cpu_model": model, "reference_1core": reference,
             "ms_per_frame": dt / frames * 1e3,
             "sample": "oracle/liboracle.so (C restatement of the reference path, gcc -O2, OpenMP %d threads = this box's cgroup CPU "
                       "quota), %d whole frames of the same workload: %d radiance rays in %.2f s" % (cores, frames, rays, dt)}
