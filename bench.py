@@ -159,7 +159,9 @@ def main():
     sync()
     dt = time.perf_counter() - t0
 
-    queued = r.last_parent_count() if r.kernel_variant().startswith("parent_queue") else 0  # before the counters are reset
+    variant = r.kernel_variant()
+    queued = r.last_parent_count() if variant in ("parent_queue_v3", "level_queues_v4") else 0  # before the counters are reset
+    level1 = r.last_level1_count() if variant == "level_queues_v4" else 0
     cnt = r.counters(reset=True)
     pipeline_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)  # everything this rank enqueues per frame before the collective
     kernel_ms, timed_launches = r.kernel_ms()                                      # the dominant kernel alone (HIP events on its stream)
@@ -184,7 +186,10 @@ def main():
         scene_bytes = info.n_spheres * 64 + info.n_point_lights * 32 + info.n_triangles * 48
         frame_bytes = W * min(H, k_max * TILE_ROWS) * 3
         n_parents = queued
-        launch_bytes = (n_parents * (64 + 3) + scene_bytes) if n_parents else (frame_bytes + scene_bytes)
+        if level1:   # leaf kernel of the level-queue pipeline: one 64-byte record read and one 12-byte slot written per level-1 hit
+            launch_bytes = level1 * (64 + 12) + scene_bytes
+        else:        # GI kernel of the parent-queue pipeline, or the single megakernel
+            launch_bytes = (n_parents * (64 + 3) + scene_bytes) if n_parents else (frame_bytes + scene_bytes)
         achieved_gbs = launch_bytes / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per launch from PMC counters cannot be collected from inside this process; the figure of the
         # last committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command is reported (N=1 only)
@@ -213,8 +218,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; FETCH doubled per the gfx950 note)" if traffic else None,
-                         "kernel": {"parent_queue_v3": "skr_gi_kernel<3, 3>", "wave_streaming_v2": "skr_wave_kernel<3, 3>"}.get(r.kernel_variant(), "skr_render_kernel<3>"), "kernel_ms": kernel_ms, "render_ms": pipeline_ms, "algorithmic_bytes_per_launch": launch_bytes, "frame_bytes": frame_bytes, "queued_parents": n_parents,
-                         "note": "HBM traffic is the parent queue (64 B per primary hit) + the u8 framebuffer + ~1 KB of scene: this path is FP32-VALU bound, see roofline_valu"},
+                         "kernel": {"level_queues_v4": "skr_leaf_kernel", "parent_queue_v3": "skr_gi_kernel<3, 3>", "wave_streaming_v2": "skr_wave_kernel<3, 3>"}.get(r.kernel_variant(), "skr_render_kernel<3>"), "kernel_ms": kernel_ms, "render_ms": pipeline_ms, "algorithmic_bytes_per_launch": launch_bytes, "frame_bytes": frame_bytes, "queued_parents": n_parents, "queued_level1_hits": level1,
+                         "note": "algorithmic HBM bytes of the dominant kernel: the level-1 hit records it reads (64 B) and the slots it writes (12 B) + ~1 KB of scene; this path is FP32-VALU bound, see roofline_valu"},
             "roofline_valu": {"bound": "fp32_valu", "achieved": alg_flop / (kernel_ms * 1e-3) / 1e12 / world * 1.0,
                               "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": alg_flop / (kernel_ms * 1e-3) / 1e12 / world / VALU_PEAK_TFLOPS,
                               "note": "algorithmic flops (34/sphere test, 150/shaded hit; shadow early-outs ignored) per GPU / peak FP32 vector"},

@@ -140,6 +140,9 @@ int skr_renderer_kernel_ms(skr_renderer *r, float *mean_ms, int32_t *launches);
 /* Number of primary sphere hits the last launch queued for the --gillum kernel (0 if that launch did not
  * use the parent queue); synchronous.  bench.py sizes the GI kernel's algorithmic HBM bytes with it. */
 int skr_renderer_last_parent_count(skr_renderer *r, uint32_t *n);
+/* Number of level-1 sphere hits the last launch (its last band) queued for the leaf kernel of the level-queue
+ * pipeline (0 for the other kernel variants); synchronous. */
+int skr_renderer_last_level1_count(skr_renderer *r, uint32_t *n);
 /* Whole frame into HOST memory (W*H*3 bytes), synchronous; what the CLI uses. */
 int skr_render_frame_host(skr_renderer *r, const skr_options *opt, uint8_t *h_rgb, float *kernel_ms);
 

@@ -11,7 +11,7 @@ EXPORTED_SYMBOLS = [
     "skr_scene_create_from_scn", "skr_scene_create_from_arrays", "skr_scene_destroy", "skr_scene_get_info",
     "skr_scene_get_arrays", "skr_scene_get_culling", "skr_options_default", "skr_radiance_ray_count", "skr_device_count",
     "skr_renderer_create", "skr_renderer_destroy", "skr_render_tiles", "skr_tile_count", "skr_render_rows",
-    "skr_renderer_read_counters", "skr_renderer_kernel_timing", "skr_renderer_kernel_ms", "skr_renderer_last_parent_count", "skr_render_frame_host", "skr_write_ppm", "skr_last_error",
+    "skr_renderer_read_counters", "skr_renderer_kernel_timing", "skr_renderer_kernel_ms", "skr_renderer_last_parent_count", "skr_renderer_last_level1_count", "skr_render_frame_host", "skr_write_ppm", "skr_last_error",
     "skr_kernel_variant", "skr_debug_eval",
 ]
 
@@ -81,6 +81,7 @@ def lib():
     L.skr_renderer_kernel_timing.argtypes = [vp, C.c_int]
     L.skr_renderer_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     L.skr_renderer_last_parent_count.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.skr_renderer_last_level1_count.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.skr_render_frame_host.argtypes = [vp, C.POINTER(COptions), vp, C.POINTER(C.c_float)]
     L.skr_write_ppm.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
     L.skr_last_error.restype = C.c_char_p
@@ -258,6 +259,11 @@ class Renderer:
     def last_parent_count(self):
         n = C.c_uint32()
         _check(lib().skr_renderer_last_parent_count(self.h, C.byref(n)), "skr_renderer_last_parent_count")
+        return n.value
+
+    def last_level1_count(self):
+        n = C.c_uint32()
+        _check(lib().skr_renderer_last_level1_count(self.h, C.byref(n)), "skr_renderer_last_level1_count")
         return n.value
 
     @staticmethod

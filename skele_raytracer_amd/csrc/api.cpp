@@ -17,6 +17,7 @@ hipError_t skr_launch_debug(int op, const void *d_in, void *d_out, uint32_t n, h
 size_t skr_render_lds_bytes(const RenderParams &p);
 bool skr_queue_selected(const RenderParams &p);
 void skr_queue_scratch_bytes(const RenderParams &p, size_t *parent_bytes, size_t *acc_bytes);
+bool skr_levels_scratch_bytes(RenderParams &p, size_t *p1_bytes, size_t *slot1_bytes);
 
 static thread_local const char *g_variant = "none";
 
@@ -42,6 +43,8 @@ struct skr_renderer {
 	int lds_limit = 0;
 	// scratch of the parent-queue pipeline, grown on demand and kept
 	void *d_parents = nullptr;
+	void *d_levels = nullptr; // level-queue pipeline: level-1 hit records + level-1 slots
+	size_t levels_cap = 0;
 	size_t parents_cap = 0;
 	float *d_acc = nullptr;
 	size_t acc_cap = 0;
@@ -112,8 +115,8 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	if(nch) memcpy(&blob[r->off_chunks], scene->tri_chunks.data(), nch * 16);
 	hipError_t e = hipMalloc((void **) &r->d_blob, blob.size() * 16);
 	if(e == hipSuccess) e = hipMemcpy(r->d_blob, blob.data(), blob.size() * 16, hipMemcpyHostToDevice);
-	if(e == hipSuccess) e = hipMalloc((void **) &r->d_counters, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long) + (SKR_PULL_QUEUES + 1) * SKR_PULL_STRIDE * sizeof(uint32_t));
-	if(e == hipSuccess) e = hipMemset(r->d_counters, 0, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long) + (SKR_PULL_QUEUES + 1) * SKR_PULL_STRIDE * sizeof(uint32_t));
+	if(e == hipSuccess) e = hipMalloc((void **) &r->d_counters, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long) + (SKR_PULL_QUEUES + 1 + SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t));
+	if(e == hipSuccess) e = hipMemset(r->d_counters, 0, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long) + (SKR_PULL_QUEUES + 1 + SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t));
 	if(e != hipSuccess)
 	{
 		skr_set_error("scene upload failed: %s", hipGetErrorString(e));
@@ -133,6 +136,7 @@ void skr_renderer_destroy(skr_renderer *r)
 	if(r->d_blob) (void) hipFree(r->d_blob);
 	if(r->d_counters) (void) hipFree(r->d_counters);
 	if(r->d_parents) (void) hipFree(r->d_parents);
+	if(r->d_levels) (void) hipFree(r->d_levels);
 	if(r->d_acc) (void) hipFree(r->d_acc);
 	for(SkrTimingHook &h : r->timed) { (void) hipEventDestroy(h.start); (void) hipEventDestroy(h.stop); }
 	for(SkrTimingHook &h : r->free_pairs) { (void) hipEventDestroy(h.start); (void) hipEventDestroy(h.stop); }
@@ -204,6 +208,8 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.first_tile = first_tile;
 	p.tile_stride = tile_stride;
 	p.out_rows = n_tiles * tile_rows;
+	p.band_row0 = 0;
+	p.band_rows = p.out_rows;
 	// main.cpp:134-137, hoisted: identical float/double expressions evaluated once
 	p.inv_width = 1 / float(opt->width);
 	p.inv_height = 1 / float(opt->height);
@@ -272,6 +278,20 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 		p.parents = reinterpret_cast<float4 *>(r->d_parents);
 		p.slot0_scratch = reinterpret_cast<float *>(reinterpret_cast<char *>(r->d_parents) + (size_t) p.width * p.out_rows * 64);
 		p.acc = r->d_acc;
+		size_t need_p1 = 0, need_slot1 = 0;
+		if(skr_levels_scratch_bytes(p, &need_p1, &need_slot1))
+		{
+			if(need_p1 + need_slot1 > r->levels_cap)
+			{
+				if(r->d_levels) SKR_HIP(hipFree(r->d_levels));
+				r->d_levels = nullptr;
+				r->levels_cap = 0;
+				SKR_HIP(hipMalloc(&r->d_levels, need_p1 + need_slot1));
+				r->levels_cap = need_p1 + need_slot1;
+			}
+			p.p1 = reinterpret_cast<float4 *>(r->d_levels);
+			p.slot1 = reinterpret_cast<float *>(reinterpret_cast<char *>(r->d_levels) + need_p1);
+		}
 	}
 	if(skr_render_lds_bytes(p) > (size_t) r->lds_limit)
 	{
@@ -355,6 +375,18 @@ int skr_renderer_last_parent_count(skr_renderer *r, uint32_t *n)
 	if(!r || !n) return SKR_ERR_ARG;
 	SKR_HIP(hipSetDevice(r->device));
 	SKR_HIP(hipMemcpy(n, r->d_counters + (size_t) SKR_COUNTER_SHARDS * 4 + 8, sizeof(uint32_t), hipMemcpyDeviceToHost));
+	return SKR_OK;
+}
+
+int skr_renderer_last_level1_count(skr_renderer *r, uint32_t *n)
+{
+	if(!r || !n) return SKR_ERR_ARG;
+	SKR_HIP(hipSetDevice(r->device));
+	std::vector<uint32_t> h((size_t) (SKR_PULL_QUEUES + 1 + SKR_P1_REGIONS) * SKR_PULL_STRIDE);
+	SKR_HIP(hipMemcpy(h.data(), r->d_counters + (size_t) SKR_COUNTER_SHARDS * 4 + 8, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	uint64_t total = 0;
+	for(uint32_t k = 0; k < SKR_P1_REGIONS; k++) total += h[(size_t) SKR_PULL_STRIDE * (1u + SKR_PULL_QUEUES + k)];
+	*n = (uint32_t) total;
 	return SKR_OK;
 }
 

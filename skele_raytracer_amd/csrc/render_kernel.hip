@@ -185,6 +185,8 @@ size_t skr_wave_lds_bytes(const RenderParams &p);
 bool skr_wave_supported(const RenderParams &p);
 hipError_t skr_launch_wave(const RenderParams &p, hipStream_t stream);
 bool skr_queue_selected(const RenderParams &p);
+bool skr_levels_selected(const RenderParams &p);
+hipError_t skr_launch_levels(const RenderParams &p, hipStream_t stream, const SkrTimingHook *hook);
 hipError_t skr_launch_queue(const RenderParams &p, hipStream_t stream, const SkrTimingHook *hook);
 
 // The wave-streaming kernel is the product path wherever it applies (depth <= 3, gillum <= 256);
@@ -213,6 +215,11 @@ hipError_t skr_launch_render(const RenderParams &p, hipStream_t stream, const ch
 {
 	if(use_wave_kernel(p))
 	{
+		if(skr_levels_selected(p) && p.parents && p.qctr && p.p1 && p.slot1)
+		{
+			*variant = "level_queues_v4";
+			return skr_launch_levels(p, stream, hook);
+		}
 		if(skr_queue_selected(p) && p.parents && p.qctr)
 		{
 			*variant = "parent_queue_v3";

@@ -16,11 +16,14 @@ struct f3 {
 #define SKR_PULL_QUEUES 16u
 #endif
 #define SKR_PULL_STRIDE 256u
+// level-queue pipeline: level-1 hits are appended to SKR_P1_REGIONS regions (one counter each, behind the pull counters)
+#define SKR_P1_REGIONS 64u
 
 struct RenderParams {
 	// image and partition (include/skr.h skr_render_tiles)
 	int32_t width, height;
 	uint32_t tile_rows, first_tile, tile_stride, out_rows;
+	uint32_t band_row0, band_rows; // skr_primary_kernel covers output rows [band_row0, band_row0 + band_rows) (the whole launch unless the level-queue pipeline works in bands)
 	int32_t tile_w_log2, tile_h_log2; // per-wave pixel tile of the streaming kernel: 8x8, 8x4 or 4x4 (set by its launcher)
 	// per-frame invariants of main.cpp:134-137, computed once on the host
 	float inv_width, inv_height, aspect, angle;
@@ -31,6 +34,10 @@ struct RenderParams {
 	const float4 *sph_geom, *sph_amb, *sph_kd, *sph_ks, *lights, *tris;
 	const float4 *tri_chunks; // the chunk tree of the triangle walk (scene_host.h): 3 float4 per node, depth-first, skip links, then 2 float4 per chunk
 	int32_t tri_chunk_size;
+	// level-queue pipeline (render_wave.hip): level-1 hit records, their region capacity (records), level-1 slots
+	float4 *p1;
+	float *slot1;
+	uint32_t p1_region_cap;
 	uint32_t gi_groups_per_slot, gi_group_round; // GI kernel group-size policy (set by skr_launch_queue)
 	int32_t tri_cones;        // some entry has a tight radius for non-grazing rays (else the cone test is compiled out of the walk)
 	int32_t n_tri_chunks;     // its node count; 0 = culling off (ray directions longer than the bounds were built for)

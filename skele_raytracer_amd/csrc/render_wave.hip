@@ -177,6 +177,7 @@ struct Wave {
 	const float *par0_tbl;                // level-1 parents of the current group: co.xyz, N.xyz, pixel, -
 	float *slot0_g;                       // != nullptr: level-1 slots of parent k, child i at slot0_g[k*3N + 3i] (HBM scratch)
 	bool q2_two_step;           // the leaf ring cannot take both halves of a pair round at once
+	bool slot_plain = false;    // SLOT_GLOBAL slots are only read by a later kernel (level-queue pipeline)
 };
 
 SKR_DEV void slot_store(const Wave &w, int slot, f3 v)
@@ -184,9 +185,17 @@ SKR_DEV void slot_store(const Wave &w, int slot, f3 v)
 	if(slot & SLOT_GLOBAL)
 	{
 		float *g = w.slot0_g + (slot & ~SLOT_GLOBAL);
-		g_store(g, v.x);
-		g_store(g + 1, v.y);
-		g_store(g + 2, v.z);
+		if(w.slot_plain)
+		{ // read by a later kernel only: one 12-byte store
+			struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+			*reinterpret_cast<F3 *>(g) = F3{v.x, v.y, v.z};
+		}
+		else
+		{
+			g_store(g, v.x);
+			g_store(g + 1, v.y);
+			g_store(g + 2, v.z);
+		}
 	}
 	else
 	{
@@ -508,17 +517,10 @@ SKR_DEV f3 sum_slots(const Wave &w, int sbase, int k)
 // DEPTH == 3: m <= 64 queued level-1 hits become the active parents (lanes [0,m)); their
 // N leaf rays each are traced in rounds, leaf hits are shaded in batches of 64, and each
 // parent's result is deposited in ITS parent's slot (raytrace.h:130).
-SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, int m, Counters &cn STAMP_ARG)
+// The m level-1 hits held by lanes [0, m) — record h, origin co0 of the ray that found it, pixel — become parents.
+SKR_DEV void expand_level1_hits(const Wave &w, int m, const HitRec &h, f3 co0, uint32_t pixel, Queue &q2, Counters &cn STAMP_ARG)
 {
-	STAMP(1);
-	wave_lds_fence();
 	const bool act = w.lane < m;
-	const HitRec h = q_read(q1, act ? w.lane : 0);
-	const int k0 = (int) ((h.ids >> 16) & 0xffu);
-	const float *p0 = w.par0_tbl + 8 * (act ? k0 : 0);
-	const f3 co0 = mk3(p0[0], p0[1], p0[2]);
-	const uint32_t pixel = __float_as_uint(p0[6]);
-	q_drop(q1, m);
 	Parent par1;
 	par1.co = par1.N = mk3(0, 0, 1);
 	par1.pixel = pixel;
@@ -587,6 +589,20 @@ SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, int m, Cou
 		wave_lds_fence();
 		STAMP(5);
 	}
+}
+
+SKR_DEV void expand_level1_batch(const Wave &w, Queue &q1, Queue &q2, int m, Counters &cn STAMP_ARG)
+{
+	STAMP(1);
+	wave_lds_fence();
+	const bool act = w.lane < m;
+	const HitRec h = q_read(q1, act ? w.lane : 0);
+	const int k0 = (int) ((h.ids >> 16) & 0xffu);
+	const float *p0 = w.par0_tbl + 8 * (act ? k0 : 0);
+	const f3 co0 = mk3(p0[0], p0[1], p0[2]);
+	const uint32_t pixel = __float_as_uint(p0[6]);
+	q_drop(q1, m);
+	expand_level1_hits(w, m, h, co0, pixel, q2, cn STAMP_PASS);
 }
 
 // All child rays (and, at depth 3, grandchild rays) of the gp parents in the wave's LDS parent table:
@@ -945,10 +961,10 @@ __global__ __launch_bounds__(256) void skr_primary_kernel(const RenderParams p)
 	const int wave = tid >> 6, lane = tid & 63;
 	const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
 	const int x = blockIdx.x * 16 + lx;
-	const uint32_t orow = blockIdx.y * 16 + ly;
+	const uint32_t brow = blockIdx.y * 16 + ly, orow = p.band_row0 + brow;
 	const uint32_t k = orow / p.tile_rows;
 	const uint32_t y = (p.first_tile + k * p.tile_stride) * p.tile_rows + (orow - k * p.tile_rows);
-	const bool valid = x < p.width && orow < p.out_rows && y < (uint32_t) p.height;
+	const bool valid = x < p.width && brow < p.band_rows && orow < p.out_rows && y < (uint32_t) p.height;
 	const uint32_t pixel = y * (uint32_t) p.width + (uint32_t) x;
 	const uint32_t out_pix = orow * (uint32_t) p.width + (uint32_t) x;
 
@@ -1170,6 +1186,285 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 	}
 }
 
+// =====================================================================================
+// Level-queue pipeline (opt-in: SKR_PIPELINE=levels; depth 3).  The parent-queue pipeline balances parents, whose
+// trees differ by a factor of 16 (17 .. 273 rays); here the tree is cut a second time, under the level-1 hits, whose
+// subtrees are all alike (N leaf rays + their shading):
+//   skr_primary_kernel   as above: 64-byte parent records
+//   skr_level1_kernel    one lane per (parent, child): traces the level-1 ray; a miss deposits its term in
+//                        slot1[parent * N + child], a sphere hit appends a 64-byte record to one of SKR_P1_REGIONS
+//                        regions (ballot + one atomic per wave; region = wave index mod 64, so a region can never
+//                        overflow: it only receives hits of its own waves)
+//   skr_leaf_kernel      one wave per 64 records of a region: shades the 64 level-1 hits full-width, traces their
+//                        64 * N leaf rays in sibling pairs, shades the leaf hits in batches of 64, deposits each
+//                        record's result in its slot1 entry (expand_level1_hits: the code the other pipelines run)
+//   skr_finalize_kernel  one lane per parent: the N slots strictly in child order, (direct/pi + 2 indirect) * kd
+// Same values, same order of every float sum: the image is bit-identical to the other paths.
+// =====================================================================================
+namespace {
+constexpr int LEAF_S1 = 512, LEAF_AW = 32, LEAF_Q2 = 192;                       // leaf slots of a window, parents per window, leaf-hit ring
+constexpr int LEAF_WAVE_FLOATS = LEAF_S1 * 3 + LEAF_AW + LEAF_Q2 * QF;
+SKR_DEV uint32_t *p1_counter(const RenderParams &p, uint32_t region) { return p.qctr + SKR_PULL_STRIDE * (1u + SKR_PULL_QUEUES + region); }
+} // namespace
+
+__global__ __launch_bounds__(256) void skr_level1_kernel(const RenderParams p)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
+	const int ns = p.n_spheres, nl = p.n_lights;
+	float4 *s_geom = lds4, *s_amb = lds4 + ns + 1, *s_kd = s_amb + ns, *s_ks = s_kd + ns, *s_lights = s_ks + ns;
+	const int tid = threadIdx.x;
+	const uint32_t N = (uint32_t) p.num_path_traces, PP = (N + 1u) >> 1; // children, sibling pairs per parent
+	const uint32_t n_pairs = p.qctr[0] * PP;
+	if((uint32_t) blockIdx.x * 256u >= n_pairs) return; // (uniform per workgroup)
+	for(int i = tid; i < ns; i += 256)
+	{
+		s_geom[i] = p.sph_geom[i];
+		s_amb[i] = p.sph_amb[i];
+		s_kd[i] = p.sph_kd[i];
+		s_ks[i] = p.sph_ks[i];
+	}
+	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
+	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	__syncthreads();
+	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
+	const int lane = tid & 63;
+	const uint32_t wave1 = (uint32_t) blockIdx.x * 4u + (uint32_t) (tid >> 6);
+	// one lane per sibling pair (children 2j, 2j+1 of a parent): one Philox call and one (e, c) per sphere for both
+	const uint32_t tp = wave1 * 64u + (uint32_t) lane;
+	const bool valid = tp < n_pairs;
+	const uint32_t parent = valid ? tp / PP : 0u, j = valid ? tp - parent * PP : 0u;
+	const uint32_t i0 = 2u * j, i1 = 2u * j + 1u;
+	const bool second = valid && i1 < N;
+	Counters cn{0, 0, 0};
+	bool hit0 = false, hit1 = false;
+	float4 rec0[3], rec1[3];
+	rec0[0] = rec0[1] = rec0[2] = rec1[0] = rec1[1] = rec1[2] = make_float4(0, 0, 0, 0);
+	if(valid)
+	{
+		const float4 *rec = p.parents + (size_t) parent * 4;
+		const float4 a0 = rec[0], a1 = rec[1], a3 = rec[3];
+		const f3 co = mk3(a0.x, a0.y, a0.z), Nn = mk3(a0.w, a1.x, a1.y);
+		const uint32_t pixel = __float_as_uint(a3.x);
+		f3 nt, nb;
+		tangent_basis(Nn, nt, nb);
+		uint32_t rnd[4];
+		philox4x32_10(pixel, p.aa_index, 0u, j, p.seed_lo, p.seed_hi, rnd); // node 0: the children of the primary hit
+		const float r1a = u31_to_unit(rnd[0]), r2a = u31_to_unit(rnd[1]), r1b = u31_to_unit(rnd[2]), r2b = u31_to_unit(rnd[3]);
+		const f3 d0 = gi_direction(r1a, r2a, Nn, nt, nb), d1 = gi_direction(r1b, r2b, Nn, nt, nb);
+		cn.rays += second ? 2u : 1u;
+		const RayPair rp = make_pair(d0, d1);
+		BestState s0, s1;
+		closest_pair_deferred(sv, co, d0, d1, second, rp, s0, s1);
+		const float pdf = (float) (1 / 3.14159265358979323846);
+#pragma nounroll
+		for(int c = 0; c < 2; c++)
+		{
+			if(c == 1 && !second) break;
+			const f3 d = c ? d1 : d0;
+			const BestState &s = c ? s1 : s0;
+			const float two_a = c ? rp.two_a.y : rp.two_a.x, four_a = c ? rp.four_a.y : rp.four_a.x, r1 = c ? r1b : r1a;
+			const uint32_t i = c ? i1 : i0, t = parent * N + i;
+			bool tri = false;
+			if(sv.nt > 0)
+			{ // raytrace.h:171-186 needs the sphere's exact t to compare against
+				const float tmin = (s.best >= 0) ? near_root_exact(two_a, s.b, s.D) : __builtin_inff();
+				tri = any_triangle_closer(sv, RayConst{co, d, two_a, four_a}, tmin);
+			}
+			if(tri || s.best < 0)
+			{ // raytrace.h:189-192 / :221-224, then :130: total += (r1 * colour) / pdf
+				const f3 colour = tri ? mk3(0, 0, 0) : p.background;
+				const f3 cc = (colour * r1) / pdf;
+				struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+				*reinterpret_cast<F3 *>(p.slot1 + (size_t) t * 3) = F3{cc.x, cc.y, cc.z};
+			}
+			else
+			{
+				float4 *o = c ? rec1 : rec0;
+				o[0] = make_float4(co.x, co.y, co.z, d.x);
+				o[1] = make_float4(d.y, d.z, s.b, s.D);
+				o[2] = make_float4(__uint_as_float((uint32_t) s.best), __uint_as_float(i), r1, __uint_as_float(pixel));
+				if(c) hit1 = true; else hit0 = true;
+			}
+		}
+	}
+	// append the wave's hits to its region: rank by ballot, one atomic per wave
+	const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+	const uint32_t region = wave1 & (SKR_P1_REGIONS - 1u);
+	const uint32_t n0h = (uint32_t) __popcll(m0), n1h = (uint32_t) __popcll(m1);
+	uint32_t base = 0;
+	if(n0h + n1h != 0u)
+	{
+		if(lane == 0) base = atomicAdd(p1_counter(p, region), n0h + n1h);
+		base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+	}
+	float4 *reg = p.p1 + (size_t) region * p.p1_region_cap * 4;
+	if(hit0)
+	{
+		float4 *dst = reg + (size_t) (base + (uint32_t) lanes_below(m0)) * 4;
+		dst[0] = rec0[0]; dst[1] = rec0[1]; dst[2] = rec0[2];
+		dst[3] = make_float4(__uint_as_float(parent * N + i0), 0.0f, 0.0f, 0.0f);
+	}
+	if(hit1)
+	{
+		float4 *dst = reg + (size_t) (base + n0h + (uint32_t) lanes_below(m1)) * 4;
+		dst[0] = rec1[0]; dst[1] = rec1[1]; dst[2] = rec1[2];
+		dst[3] = make_float4(__uint_as_float(parent * N + i1), 0.0f, 0.0f, 0.0f);
+	}
+	if(p.counters)
+	{
+		const uint32_t a = wave_sum(cn.rays);
+		if(lane == 0 && a) atomicAdd(&p.counters[4u * (wave1 & (SKR_COUNTER_SHARDS - 1u))], (unsigned long long) a);
+	}
+}
+
+__global__ __launch_bounds__(256, 3) void skr_leaf_kernel(const RenderParams p)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
+	const int ns = p.n_spheres, nl = p.n_lights;
+	float4 *s_geom = lds4, *s_amb = lds4 + ns + 1, *s_kd = s_amb + ns, *s_ks = s_kd + ns, *s_lights = s_ks + ns;
+	const int tid = threadIdx.x;
+	// unit = 64 records of a region; wave g of the grid (a multiple of the region count) owns region g mod R and takes
+	// its units g / R, g / R + G / R, ... — the units are all alike (64 level-1 hits, 64 N leaf rays), so a static
+	// stride balances, and the scene is staged once per workgroup instead of once per unit
+	for(int i = tid; i < ns; i += 256)
+	{
+		s_geom[i] = p.sph_geom[i];
+		s_amb[i] = p.sph_amb[i];
+		s_kd[i] = p.sph_kd[i];
+		s_ks[i] = p.sph_ks[i];
+	}
+	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
+	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	__syncthreads(); // the only workgroup barrier
+	const int wave = tid >> 6, lane = tid & 63;
+	const uint32_t g = (uint32_t) blockIdx.x * 4u + (uint32_t) wave, n_waves = gridDim.x * 4u;
+	const uint32_t region = g & (SKR_P1_REGIONS - 1u);
+	const uint32_t cnt = *p1_counter(p, region);
+	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * LEAF_WAVE_FLOATS;
+	Wave w;
+	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
+	w.p = &p;
+	w.slots = wbase;
+	w.lane = lane;
+	w.N = p.num_path_traces;
+	w.magicN = (uint32_t) (((1u << 24) + (uint32_t) w.N - 1u) / (uint32_t) w.N);
+	{
+		const uint32_t pp = (uint32_t) (w.N + 1) >> 1;
+		w.magicPP = ((1u << 24) + pp - 1u) / pp;
+	}
+	w.aa = p.aa_index;
+	w.pdf = (float) (1 / 3.14159265358979323846);
+	w.s0_max = 0;
+	w.s1_max = LEAF_S1;
+	w.sbase1 = 0;
+	w.q2_two_step = false;
+	w.par0_max = 0;
+	w.aw_max = LEAF_AW;
+	w.act_max = 64;
+	w.par0_tbl = nullptr;
+	w.slot0_g = p.slot1; // a record's result goes to slot1[3 t] (SLOT_GLOBAL offsets)
+	w.slot_plain = true;
+	Queue q2{wbase + LEAF_S1 * 3 + LEAF_AW, LEAF_Q2, 0, 0};
+	Counters cn{0, 0, 0};
+	STAMP_DECL;
+	const uint32_t ustep = (n_waves / SKR_P1_REGIONS) * 64u;
+	const float4 *reg = p.p1 + (size_t) region * p.p1_region_cap * 4;
+	for(uint32_t first = (g / SKR_P1_REGIONS) * 64u; first < cnt; first += ustep)
+	{
+	const int m = (int) (cnt - first < 64u ? cnt - first : 64u);
+	HitRec h;
+	h.d = mk3(0, 0, 1);
+	h.b = h.D = h.r1 = 0.0f;
+	h.ids = 0;
+	h.slot = SLOT_GLOBAL;
+	f3 co0 = mk3(0, 0, 0);
+	uint32_t pixel = 0;
+	if(lane < m)
+	{ // (prefetching the next unit's records one unit ahead was measured: no gain, the other waves of the SIMD cover the wait)
+		typedef float v4f __attribute__((ext_vector_type(4)));
+		const v4f *rv = reinterpret_cast<const v4f *>(reg + (size_t) (first + (uint32_t) lane) * 4);
+		const v4f n0 = __builtin_nontemporal_load(&rv[0]), n1 = __builtin_nontemporal_load(&rv[1]), n2 = __builtin_nontemporal_load(&rv[2]),
+				  n3 = __builtin_nontemporal_load(&rv[3]);
+		co0 = mk3(n0.x, n0.y, n0.z);
+		h.d = mk3(n0.w, n1.x, n1.y);
+		h.b = n1.z;
+		h.D = n1.w;
+		h.ids = (__float_as_uint(n2.x) & 0xffffu) | (__float_as_uint(n2.y) << 24); // sphere | child index << 24
+		h.r1 = n2.z;
+		pixel = __float_as_uint(n2.w);
+		h.slot = SLOT_GLOBAL | (int) (__float_as_uint(n3.x) * 3u);
+	}
+	STAMP(0);
+	expand_level1_hits(w, m, h, co0, pixel, q2, cn STAMP_PASS);
+	}
+#if defined(SKR_STAMPS) && SKR_STAMPS
+	if(p.counters && lane == 0)
+		for(int k = 0; k < 8; k++) atomicAdd(&p.counters[4u * SKR_COUNTER_SHARDS + k], st_acc[k]);
+#endif
+	if(p.counters)
+	{
+		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays);
+		if(lane == 0)
+		{
+			unsigned long long *c4 = p.counters + 4u * (g & (SKR_COUNTER_SHARDS - 1u));
+			atomicAdd(&c4[0], (unsigned long long) a);
+			atomicAdd(&c4[1], (unsigned long long) b);
+			atomicAdd(&c4[2], (unsigned long long) c);
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void skr_finalize_kernel(const RenderParams p)
+{ // a wave = 64 parents; their slots are read as one contiguous run (coalesced), 16 children at a time, through LDS
+	__shared__ float s_t[4][64 * 49];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const uint32_t n0 = p.qctr[0];
+	const uint32_t parent0 = ((uint32_t) blockIdx.x * 4u + (uint32_t) wave) * 64u;
+	if(parent0 >= n0) return;
+	const uint32_t parent = parent0 + (uint32_t) lane;
+	const bool valid = parent < n0;
+	const int N = p.num_path_traces;
+	float *mine = s_t[wave];
+	f3 total = mk3(0, 0, 0);
+	for(int c0 = 0; c0 < N; c0 += 16)
+	{
+		const int nc = (N - c0 < 16) ? N - c0 : 16, run = 3 * nc; // floats of one parent in this chunk
+		const size_t chunk0 = ((size_t) parent0 * N + c0) * 3; // first float of the wave's run in this chunk
+		if((run & 3) == 0 && ((3 * N) & 3) == 0)
+		{ // 16-byte loads: run / 4 float4 per parent
+			const int run4 = run >> 2;
+			for(int idx = lane; idx < 64 * run4; idx += 64)
+			{
+				const int pl = idx / run4, q = idx - pl * run4;
+				if(parent0 + (uint32_t) pl < n0)
+				{
+					const float4 v = *reinterpret_cast<const float4 *>(p.slot1 + chunk0 + (size_t) pl * 3 * N + 4 * q);
+					float *d = mine + pl * 49 + 4 * q;
+					d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+				}
+			}
+		}
+		else
+			for(int idx = lane; idx < 64 * run; idx += 64)
+			{
+				const int pl = idx / run, off = idx - pl * run;
+				if(parent0 + (uint32_t) pl < n0) mine[pl * 49 + off] = p.slot1[chunk0 + (size_t) pl * 3 * N + off];
+			}
+		wave_lds_fence();
+		if(valid)
+			for(int i = 0; i < nc; i++) total = total + mk3(mine[lane * 49 + 3 * i], mine[lane * 49 + 3 * i + 1], mine[lane * 49 + 3 * i + 2]); // raytrace.h:130, child order
+		wave_lds_fence();
+	}
+	if(!valid) return;
+	const float4 *rec = p.parents + (size_t) parent * 4;
+	const float4 a1 = rec[1], a2 = rec[2], a3 = rec[3];
+	const f3 direct0 = mk3(a1.z, a1.w, a2.x), kd0 = mk3(a2.y, a2.z, a2.w);
+	total = total / (float) N;
+	emit_sample(p, __float_as_uint(a3.y), (direct0 / (float) 3.14159265358979323846 + total * 2.0f) * kd0); // raytrace.h:213
+}
+
 // AA only: image[y][x] /= g*g (main.cpp:165), then the quantiser (main.cpp:205).
 __global__ __launch_bounds__(256) void skr_resolve_kernel(const RenderParams p)
 {
@@ -1293,6 +1588,93 @@ void skr_queue_scratch_bytes(const RenderParams &p, size_t *parent_bytes, size_t
 	// parent records, then the GI kernel's per-wave level-1 slot scratch (768 workgroups x 4 waves x 32 parents x N x float3)
 	*parent_bytes = pixels * 64 + (size_t) 256 * 3 * 4 * 32 * 3 * sizeof(float) * (size_t) (p.num_path_traces > 0 ? p.num_path_traces : 1);
 	*acc_bytes = p.grid_size > 0 ? pixels * 12 : 0;
+}
+
+// ---- level-queue pipeline: selection, scratch, launch
+static uint32_t levels_band_rows(const RenderParams &p)
+{ // rows per band: the level-1 records of a band (64 B x 2 x width x N / 2 per row, every pixel a parent, every child a hit)
+  // stay within ~3 GiB; a 1080p --gillum 16 frame is one band, 4K --gillum 64 works in bands of ~200 rows
+	uint64_t budget = 3ull << 30;
+	if(const char *e = getenv("SKR_LEVELS_BUDGET_MB")) budget = (uint64_t) (atoi(e) > 0 ? atoi(e) : 1) << 20; // tests: force several bands
+	const uint64_t per_row = (uint64_t) p.width * (uint64_t) (((p.num_path_traces + 1) >> 1) * 2) * 64;
+	uint64_t rows = budget / (per_row ? per_row : 1);
+	rows = rows / 16 * 16;
+	if(rows < 16) rows = 16;
+	return (uint32_t) (rows < p.out_rows ? rows : p.out_rows);
+}
+static uint64_t levels_pairs_max(const RenderParams &p, uint32_t rows)
+{ // every pixel of the band could be a parent
+	return (uint64_t) p.width * rows * (uint64_t) (((p.num_path_traces > 0 ? p.num_path_traces : 1) + 1) >> 1);
+}
+static uint64_t levels_tasks_max(const RenderParams &p, uint32_t rows)
+{ // record capacity: a region receives at most 128 hits from each of its skr_level1_kernel waves (64 sibling pairs)
+	const uint64_t waves = (levels_pairs_max(p, rows) + 63) / 64;
+	return (waves + SKR_P1_REGIONS - 1) / SKR_P1_REGIONS * 128 * SKR_P1_REGIONS;
+}
+
+// Default for --gillum at depth 3 on sphere scenes (measured against the parent-queue pipeline, 1080p: headline 2.54 ->
+// 2.42 ms, no shadows 1.98 -> 1.85, bear 1.02 -> 0.63, gillum 4 / 8 / 64 / 255: -37 / -16 / -17 / -46 %, one rank's 1/8 frame
+// 0.46 -> 0.41); triangle scenes stay on the parent-queue pipeline (test.scn: 1.5 vs 2.8 ms — their rounds are long
+// and few).  SKR_PIPELINE=levels | queue | mega forces one.
+bool skr_levels_selected(const RenderParams &p)
+{
+	const char *e = getenv("SKR_PIPELINE");
+	const bool forced = e && !strcmp(e, "levels");
+	if(e && !forced) return false;
+	if(!(skr_wave_supported(p) && p.monte_carlo && p.n_spheres > 0 && p.max_depth == 3 && p.num_path_traces > 0 && p.num_path_traces <= 255)) return false;
+	if(p.n_tris > 0 && !forced) return false;
+	return levels_tasks_max(p, levels_band_rows(p)) * 3 < (1ull << 30);
+}
+
+bool skr_levels_scratch_bytes(RenderParams &p, size_t *p1_bytes, size_t *slot1_bytes)
+{
+	if(!skr_levels_selected(p)) return false;
+	const uint32_t rows = levels_band_rows(p);
+	const uint64_t t = levels_tasks_max(p, rows);
+	p.p1_region_cap = (uint32_t) (t / SKR_P1_REGIONS);
+	*p1_bytes = (size_t) t * 64;
+	*slot1_bytes = (size_t) p.width * rows * (size_t) p.num_path_traces * 12;
+	return true;
+}
+
+hipError_t skr_launch_levels(const RenderParams &p_in, hipStream_t stream, const SkrTimingHook *hook)
+{
+	RenderParams p = p_in;
+	const int nsamp = p.grid_size > 0 ? p.grid_size * p.grid_size : 1;
+	const size_t lds_scene = ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 32;
+	const size_t lds_leaf = lds_scene + (size_t) 4 * LEAF_WAVE_FLOATS * sizeof(float);
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(skr_leaf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_leaf);
+	if(e != hipSuccess) return e;
+	const uint32_t band = levels_band_rows(p);
+	for(int s = 0; s < nsamp; s++)
+	{
+		p.aa_index = (uint32_t) s;
+		for(uint32_t row0 = 0; row0 < p.out_rows; row0 += band)
+		{ // every band is a complete pass: its parents, their level-1 hits, their pixels
+			p.band_row0 = row0;
+			p.band_rows = p.out_rows - row0 < band ? p.out_rows - row0 : band;
+			const uint64_t pixels = (uint64_t) p.width * p.band_rows;
+			const bool last = s == nsamp - 1 && row0 + band >= p.out_rows;
+			e = hipMemsetAsync(p.qctr, 0, (SKR_PULL_QUEUES + 1 + SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t), stream);
+			if(e != hipSuccess) return e;
+			hipLaunchKernelGGL(skr_primary_kernel, dim3((p.width + 15) / 16, (p.band_rows + 15) / 16), dim3(256), lds_scene, stream, p);
+			hipLaunchKernelGGL(skr_level1_kernel, dim3((unsigned) ((levels_pairs_max(p, p.band_rows) + 255) / 256)), dim3(256), lds_scene, stream, p);
+			// the leaf kernel is the dominant one: time it alone (the last band's launch when there are several)
+			if(hook && hook->start && last) (void) hipEventRecord(hook->start, stream);
+			hipLaunchKernelGGL(skr_leaf_kernel, dim3(256u * 3u * 4u), dim3(256), lds_leaf, stream, p); // 4 x resident; a multiple of SKR_P1_REGIONS / 4
+			if(hook && hook->stop && last) (void) hipEventRecord(hook->stop, stream);
+			hipLaunchKernelGGL(skr_finalize_kernel, dim3((unsigned) ((pixels + 255) / 256)), dim3(256), 0, stream, p);
+			e = hipGetLastError();
+			if(e != hipSuccess) return e;
+		}
+	}
+	if(p.grid_size > 0)
+	{
+		const size_t n = (size_t) p.width * p.out_rows;
+		hipLaunchKernelGGL(skr_resolve_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, p);
+		return hipGetLastError();
+	}
+	return hipSuccess;
 }
 
 template <int D, int OCC>

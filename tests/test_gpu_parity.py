@@ -254,15 +254,17 @@ def test_full_size_config5_rows_against_oracle(gpu, oracle):
 
 
 def test_all_kernel_variants_agree(gpu, monkeypatch):
-    """The product has one arithmetic spec and several schedules: the parent-queue pipeline (default for
-    --gillum), the single wave-streaming megakernel with each per-wave tile shape and each LDS/VGPR budget,
-    and the per-pixel kernel.  Every one of them must produce the same bits and the same ray counts."""
+    """The product has one arithmetic spec and several schedules: the level-queue pipeline (default for --gillum at
+    depth 3 on sphere scenes; in one band or several), the parent-queue pipeline, the single wave-streaming megakernel
+    with each per-wave tile shape and each LDS/VGPR budget, and the per-pixel kernel.  Every one of them must produce
+    the same bits and the same ray counts."""
     w, h = 176, 99
     opt = skr.Options(w, h, gillum=8, shadow=True, seed=31)
     r = renderer("spheres2.scn")
+    knobs = ("SKR_PIPELINE", "SKR_KERNEL", "SKR_OCC", "SKR_TILE", "SKR_LEVELS_BUDGET_MB")
 
     def run(env):
-        for k in ("SKR_PIPELINE", "SKR_KERNEL", "SKR_OCC", "SKR_TILE"):
+        for k in knobs:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -272,16 +274,42 @@ def test_all_kernel_variants_agree(gpu, monkeypatch):
         return rgb.cpu().numpy(), rgbf.cpu().numpy().view(np.uint32), r.counters(), r.kernel_variant()
 
     base = run({})
-    assert base[3] == "parent_queue_v3"
+    assert base[3] == "level_queues_v4"
     seen = {base[3]}
-    for env in ({"SKR_PIPELINE": "mega"}, {"SKR_PIPELINE": "mega", "SKR_TILE": "64"}, {"SKR_PIPELINE": "mega", "SKR_TILE": "16"},
-                {"SKR_PIPELINE": "mega", "SKR_OCC": "2"}, {"SKR_OCC": "2"}, {"SKR_OCC": "3"}, {"SKR_KERNEL": "v1"}):
+    for env in ({"SKR_LEVELS_BUDGET_MB": "1"},  # 1 MiB of level-1 records: 16-row bands, 7 of them
+                {"SKR_PIPELINE": "queue"}, {"SKR_PIPELINE": "queue", "SKR_OCC": "2"}, {"SKR_PIPELINE": "queue", "SKR_OCC": "3"},
+                {"SKR_PIPELINE": "mega"}, {"SKR_PIPELINE": "mega", "SKR_TILE": "64"}, {"SKR_PIPELINE": "mega", "SKR_TILE": "16"},
+                {"SKR_PIPELINE": "mega", "SKR_OCC": "2"}, {"SKR_KERNEL": "v1"}):
         got = run(env)
         seen.add(got[3])
         assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
         assert got[2] == base[2], env
-    assert seen == {"parent_queue_v3", "wave_streaming_v2", "lane_per_pixel_dfs_v1f"}
-    for k in ("SKR_PIPELINE", "SKR_KERNEL", "SKR_OCC", "SKR_TILE"):
+    assert seen == {"level_queues_v4", "parent_queue_v3", "wave_streaming_v2", "lane_per_pixel_dfs_v1f"}
+    for k in knobs:
+        monkeypatch.delenv(k, raising=False)
+
+
+def test_level_queue_pipeline_in_bands_and_on_triangles(gpu, oracle, monkeypatch):
+    """The default --gillum path against the oracle where it is not the default or not in one piece: forced onto a
+    triangle scene (SKR_PIPELINE=levels), in 16-row bands with AA (several bands x several samples), and with an odd N."""
+    for scn, w, h, kw, env in (("test.scn", 96, 54, dict(gillum=4, shadow=True, seed=3), {"SKR_PIPELINE": "levels"}),
+                               ("spheres2.scn", 200, 113, dict(gillum=6, jsample=2, shadow=True, seed=9), {"SKR_LEVELS_BUDGET_MB": "1"}),
+                               ("spheres2.scn", 131, 77, dict(gillum=5, shadow=True, seed=4), {"SKR_LEVELS_BUDGET_MB": "2"}),
+                               ("bear.scn", 160, 90, dict(gillum=255, seed=4), {})):
+        for k in ("SKR_PIPELINE", "SKR_LEVELS_BUDGET_MB"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = renderer(scn)
+        r.counters(reset=True)
+        rgb, rgbf = r.render(skr.Options(w, h, **kw), want_float=True)
+        gpu.cuda.synchronize()
+        assert r.kernel_variant() == "level_queues_v4"
+        o_rgb, o_f, st = oracle.render(scene_path(scn), w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, **kw)
+        compare(rgb.cpu().numpy(), rgbf.cpu().numpy(), o_rgb, o_f, "%s %s %s" % (scn, kw, env))
+        cnt = r.counters()
+        assert cnt["radiance_rays"] == int(st[0]) and cnt["sphere_hits"] == int(st[1])
+    for k in ("SKR_PIPELINE", "SKR_LEVELS_BUDGET_MB"):
         monkeypatch.delenv(k, raising=False)
 
 
