@@ -1205,6 +1205,7 @@ namespace {
 constexpr int LEAF_S1 = 512, LEAF_AW = 32, LEAF_Q2 = 192;                       // leaf slots of a window, parents per window, leaf-hit ring
 constexpr int LEAF_WAVE_FLOATS = LEAF_S1 * 3 + LEAF_AW + LEAF_Q2 * QF;
 SKR_DEV uint32_t *p1_counter(const RenderParams &p, uint32_t region) { return p.qctr + SKR_PULL_STRIDE * (1u + SKR_PULL_QUEUES + region); }
+SKR_DEV uint32_t *p1_taken(const RenderParams &p, uint32_t region) { return p.qctr + SKR_PULL_STRIDE * (1u + SKR_PULL_QUEUES + SKR_P1_REGIONS + region); } // units handed out
 } // namespace
 
 __global__ __launch_bounds__(256) void skr_level1_kernel(const RenderParams p)
@@ -1325,9 +1326,10 @@ __global__ __launch_bounds__(256, 3) void skr_leaf_kernel(const RenderParams p)
 	const int ns = p.n_spheres, nl = p.n_lights;
 	float4 *s_geom = lds4, *s_amb = lds4 + ns + 1, *s_kd = s_amb + ns, *s_ks = s_kd + ns, *s_lights = s_ks + ns;
 	const int tid = threadIdx.x;
-	// unit = 64 records of a region; wave g of the grid (a multiple of the region count) owns region g mod R and takes
-	// its units g / R, g / R + G / R, ... — the units are all alike (64 level-1 hits, 64 N leaf rays), so a static
-	// stride balances, and the scene is staged once per workgroup instead of once per unit
+	// unit = 64 records of a region.  Persistent waves: wave g starts at region g mod R and pulls that region's next
+	// unit with one atomic; when the region is exhausted it moves on to the next one, until all R are.  The units are
+	// all alike (64 level-1 hits, 64 N leaf rays), and a small launch has only a few per wave: pulling keeps the last
+	// wave from being a whole unit late.
 	for(int i = tid; i < ns; i += 256)
 	{
 		s_geom[i] = p.sph_geom[i];
@@ -1339,9 +1341,8 @@ __global__ __launch_bounds__(256, 3) void skr_leaf_kernel(const RenderParams p)
 	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	__syncthreads(); // the only workgroup barrier
 	const int wave = tid >> 6, lane = tid & 63;
-	const uint32_t g = (uint32_t) blockIdx.x * 4u + (uint32_t) wave, n_waves = gridDim.x * 4u;
-	const uint32_t region = g & (SKR_P1_REGIONS - 1u);
-	const uint32_t cnt = *p1_counter(p, region);
+	const uint32_t g = (uint32_t) blockIdx.x * 4u + (uint32_t) wave;
+	uint32_t region = g & (SKR_P1_REGIONS - 1u), dry = 0;
 	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * LEAF_WAVE_FLOATS;
 	Wave w;
 	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
@@ -1369,10 +1370,21 @@ __global__ __launch_bounds__(256, 3) void skr_leaf_kernel(const RenderParams p)
 	Queue q2{wbase + LEAF_S1 * 3 + LEAF_AW, LEAF_Q2, 0, 0};
 	Counters cn{0, 0, 0};
 	STAMP_DECL;
-	const uint32_t ustep = (n_waves / SKR_P1_REGIONS) * 64u;
-	const float4 *reg = p.p1 + (size_t) region * p.p1_region_cap * 4;
-	for(uint32_t first = (g / SKR_P1_REGIONS) * 64u; first < cnt; first += ustep)
+	for(;;)
 	{
+	uint32_t first = 0, cnt = 0;
+	for(;;)
+	{ // wave-uniform
+		cnt = *p1_counter(p, region);
+		uint32_t k = 0;
+		if(lane == 0) k = atomicAdd(p1_taken(p, region), 1u);
+		first = (uint32_t) __builtin_amdgcn_readfirstlane((int) k) * 64u;
+		if(first < cnt) break;
+		region = (region + 1u) & (SKR_P1_REGIONS - 1u);
+		if(++dry == SKR_P1_REGIONS) break;
+	}
+	if(dry == SKR_P1_REGIONS) break;
+	const float4 *reg = p.p1 + (size_t) region * p.p1_region_cap * 4;
 	const int m = (int) (cnt - first < 64u ? cnt - first : 64u);
 	HitRec h;
 	h.d = mk3(0, 0, 1);
@@ -1655,13 +1667,13 @@ hipError_t skr_launch_levels(const RenderParams &p_in, hipStream_t stream, const
 			p.band_rows = p.out_rows - row0 < band ? p.out_rows - row0 : band;
 			const uint64_t pixels = (uint64_t) p.width * p.band_rows;
 			const bool last = s == nsamp - 1 && row0 + band >= p.out_rows;
-			e = hipMemsetAsync(p.qctr, 0, (SKR_PULL_QUEUES + 1 + SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t), stream);
+			e = hipMemsetAsync(p.qctr, 0, (SKR_PULL_QUEUES + 1 + 2 * SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t), stream);
 			if(e != hipSuccess) return e;
 			hipLaunchKernelGGL(skr_primary_kernel, dim3((p.width + 15) / 16, (p.band_rows + 15) / 16), dim3(256), lds_scene, stream, p);
 			hipLaunchKernelGGL(skr_level1_kernel, dim3((unsigned) ((levels_pairs_max(p, p.band_rows) + 255) / 256)), dim3(256), lds_scene, stream, p);
 			// the leaf kernel is the dominant one: time it alone (the last band's launch when there are several)
 			if(hook && hook->start && last) (void) hipEventRecord(hook->start, stream);
-			hipLaunchKernelGGL(skr_leaf_kernel, dim3(256u * 3u * 4u), dim3(256), lds_leaf, stream, p); // 4 x resident; a multiple of SKR_P1_REGIONS / 4
+			hipLaunchKernelGGL(skr_leaf_kernel, dim3(256u * 3u), dim3(256), lds_leaf, stream, p); // every workgroup resident
 			if(hook && hook->stop && last) (void) hipEventRecord(hook->stop, stream);
 			hipLaunchKernelGGL(skr_finalize_kernel, dim3((unsigned) ((pixels + 255) / 256)), dim3(256), 0, stream, p);
 			e = hipGetLastError();

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B: level-queue pipeline (SKR_PIPELINE=levels) against the default path — same bytes? how fast? (development aid)"""
+"""A/B: level-queue pipeline (SKR_PIPELINE=levels) against the parent-queue pipeline (SKR_PIPELINE=queue) — same bytes? how fast? (development aid)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,10 +13,7 @@ def run(scn, w, h, G=1, reps=5, **kw):
     n = r.tile_count(opt, 8, 0, G)
     outs = {}
     for mode in ("default", "levels"):
-        if mode == "levels":
-            os.environ["SKR_PIPELINE"] = "levels"
-        else:
-            os.environ.pop("SKR_PIPELINE", None)
+        os.environ["SKR_PIPELINE"] = "levels" if mode == "levels" else "queue"
         buf = torch.zeros((n * 8, w, 3), dtype=torch.uint8, device="cuda")
         fb = torch.zeros((n * 8, w, 3), dtype=torch.float32, device="cuda")
         st = torch.cuda.current_stream()
