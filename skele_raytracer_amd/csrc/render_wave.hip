@@ -1372,44 +1372,44 @@ __global__ __launch_bounds__(256, 3) void skr_leaf_kernel(const RenderParams p)
 	STAMP_DECL;
 	for(;;)
 	{
-	uint32_t first = 0, cnt = 0;
-	for(;;)
-	{ // wave-uniform
-		cnt = *p1_counter(p, region);
-		uint32_t k = 0;
-		if(lane == 0) k = atomicAdd(p1_taken(p, region), 1u);
-		first = (uint32_t) __builtin_amdgcn_readfirstlane((int) k) * 64u;
-		if(first < cnt) break;
-		region = (region + 1u) & (SKR_P1_REGIONS - 1u);
-		if(++dry == SKR_P1_REGIONS) break;
-	}
-	if(dry == SKR_P1_REGIONS) break;
-	const float4 *reg = p.p1 + (size_t) region * p.p1_region_cap * 4;
-	const int m = (int) (cnt - first < 64u ? cnt - first : 64u);
-	HitRec h;
-	h.d = mk3(0, 0, 1);
-	h.b = h.D = h.r1 = 0.0f;
-	h.ids = 0;
-	h.slot = SLOT_GLOBAL;
-	f3 co0 = mk3(0, 0, 0);
-	uint32_t pixel = 0;
-	if(lane < m)
-	{ // (prefetching the next unit's records one unit ahead was measured: no gain, the other waves of the SIMD cover the wait)
-		typedef float v4f __attribute__((ext_vector_type(4)));
-		const v4f *rv = reinterpret_cast<const v4f *>(reg + (size_t) (first + (uint32_t) lane) * 4);
-		const v4f n0 = __builtin_nontemporal_load(&rv[0]), n1 = __builtin_nontemporal_load(&rv[1]), n2 = __builtin_nontemporal_load(&rv[2]),
-				  n3 = __builtin_nontemporal_load(&rv[3]);
-		co0 = mk3(n0.x, n0.y, n0.z);
-		h.d = mk3(n0.w, n1.x, n1.y);
-		h.b = n1.z;
-		h.D = n1.w;
-		h.ids = (__float_as_uint(n2.x) & 0xffffu) | (__float_as_uint(n2.y) << 24); // sphere | child index << 24
-		h.r1 = n2.z;
-		pixel = __float_as_uint(n2.w);
-		h.slot = SLOT_GLOBAL | (int) (__float_as_uint(n3.x) * 3u);
-	}
-	STAMP(0);
-	expand_level1_hits(w, m, h, co0, pixel, q2, cn STAMP_PASS);
+		uint32_t first = 0, cnt = 0;
+		for(;;)
+		{ // pull the next unit (wave-uniform): this region's, or the next region's once this one is exhausted
+			cnt = *p1_counter(p, region);
+			uint32_t k = 0;
+			if(lane == 0) k = atomicAdd(p1_taken(p, region), 1u);
+			first = (uint32_t) __builtin_amdgcn_readfirstlane((int) k) * 64u;
+			if(first < cnt) break;
+			region = (region + 1u) & (SKR_P1_REGIONS - 1u);
+			if(++dry == SKR_P1_REGIONS) break;
+		}
+		if(dry == SKR_P1_REGIONS) break;
+		const float4 *reg = p.p1 + (size_t) region * p.p1_region_cap * 4;
+		const int m = (int) (cnt - first < 64u ? cnt - first : 64u);
+		HitRec h;
+		h.d = mk3(0, 0, 1);
+		h.b = h.D = h.r1 = 0.0f;
+		h.ids = 0;
+		h.slot = SLOT_GLOBAL;
+		f3 co0 = mk3(0, 0, 0);
+		uint32_t pixel = 0;
+		if(lane < m)
+		{ // (fetching the next unit's records one unit ahead was measured: no gain, the other waves of the SIMD cover the wait)
+			typedef float v4f __attribute__((ext_vector_type(4)));
+			const v4f *rv = reinterpret_cast<const v4f *>(reg + (size_t) (first + (uint32_t) lane) * 4);
+			const v4f n0 = __builtin_nontemporal_load(&rv[0]), n1 = __builtin_nontemporal_load(&rv[1]), n2 = __builtin_nontemporal_load(&rv[2]),
+					  n3 = __builtin_nontemporal_load(&rv[3]);
+			co0 = mk3(n0.x, n0.y, n0.z);
+			h.d = mk3(n0.w, n1.x, n1.y);
+			h.b = n1.z;
+			h.D = n1.w;
+			h.ids = (__float_as_uint(n2.x) & 0xffffu) | (__float_as_uint(n2.y) << 24); // sphere | child index << 24
+			h.r1 = n2.z;
+			pixel = __float_as_uint(n2.w);
+			h.slot = SLOT_GLOBAL | (int) (__float_as_uint(n3.x) * 3u);
+		}
+		STAMP(0);
+		expand_level1_hits(w, m, h, co0, pixel, q2, cn STAMP_PASS);
 	}
 #if defined(SKR_STAMPS) && SKR_STAMPS
 	if(p.counters && lane == 0)
