@@ -1,4 +1,4 @@
-set -e
+set -e -o pipefail
 cd $GRAFT_REPO_ROOT
 timeout -k 10 500 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2

@@ -1,5 +1,5 @@
 # Separate rocprofv3 --pmc passes (never combined with tracing) for the bench workload; summaries land in gpurun_out/.
-set -e
+set -e -o pipefail
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_final

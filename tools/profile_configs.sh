@@ -1,4 +1,4 @@
-set -e
+set -e -o pipefail
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for c in 2 4; do
