@@ -1208,6 +1208,8 @@ SKR_DEV uint32_t *p1_counter(const RenderParams &p, uint32_t region) { return p.
 SKR_DEV uint32_t *p1_taken(const RenderParams &p, uint32_t region) { return p.qctr + SKR_PULL_STRIDE * (1u + SKR_PULL_QUEUES + SKR_P1_REGIONS + region); } // units handed out
 } // namespace
 
+// TRIS = false: the scene has no triangles (the launcher's default case) and the walk is compiled out.
+template <bool TRIS>
 __global__ __launch_bounds__(256) void skr_level1_kernel(const RenderParams p)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1228,7 +1230,7 @@ __global__ __launch_bounds__(256) void skr_level1_kernel(const RenderParams p)
 	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
 	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	__syncthreads();
-	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
+	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
 	const int lane = tid & 63;
 	const uint32_t wave1 = (uint32_t) blockIdx.x * 4u + (uint32_t) (tid >> 6);
 	// one lane per sibling pair (children 2j, 2j+1 of a parent): one Philox call and one (e, c) per sphere for both
@@ -1319,6 +1321,7 @@ __global__ __launch_bounds__(256) void skr_level1_kernel(const RenderParams p)
 	}
 }
 
+template <bool TRIS>
 __global__ __launch_bounds__(256, 3) void skr_leaf_kernel(const RenderParams p)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1345,7 +1348,7 @@ __global__ __launch_bounds__(256, 3) void skr_leaf_kernel(const RenderParams p)
 	uint32_t region = g & (SKR_P1_REGIONS - 1u), dry = 0;
 	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * LEAF_WAVE_FLOATS;
 	Wave w;
-	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
+	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
 	w.p = &p;
 	w.slots = wbase;
 	w.lane = lane;
@@ -1655,7 +1658,9 @@ hipError_t skr_launch_levels(const RenderParams &p_in, hipStream_t stream, const
 	const int nsamp = p.grid_size > 0 ? p.grid_size * p.grid_size : 1;
 	const size_t lds_scene = ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 32;
 	const size_t lds_leaf = lds_scene + (size_t) 4 * LEAF_WAVE_FLOATS * sizeof(float);
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(skr_leaf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_leaf);
+	const bool tris = p.n_tris > 0;
+	hipError_t e = hipFuncSetAttribute(tris ? reinterpret_cast<const void *>(skr_leaf_kernel<true>) : reinterpret_cast<const void *>(skr_leaf_kernel<false>),
+									   hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_leaf);
 	if(e != hipSuccess) return e;
 	const uint32_t band = levels_band_rows(p);
 	for(int s = 0; s < nsamp; s++)
@@ -1670,10 +1675,13 @@ hipError_t skr_launch_levels(const RenderParams &p_in, hipStream_t stream, const
 			e = hipMemsetAsync(p.qctr, 0, (SKR_PULL_QUEUES + 1 + 2 * SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t), stream);
 			if(e != hipSuccess) return e;
 			hipLaunchKernelGGL(skr_primary_kernel, dim3((p.width + 15) / 16, (p.band_rows + 15) / 16), dim3(256), lds_scene, stream, p);
-			hipLaunchKernelGGL(skr_level1_kernel, dim3((unsigned) ((levels_pairs_max(p, p.band_rows) + 255) / 256)), dim3(256), lds_scene, stream, p);
+			const dim3 grid1((unsigned) ((levels_pairs_max(p, p.band_rows) + 255) / 256));
+			if(tris) hipLaunchKernelGGL(skr_level1_kernel<true>, grid1, dim3(256), lds_scene, stream, p);
+			else hipLaunchKernelGGL(skr_level1_kernel<false>, grid1, dim3(256), lds_scene, stream, p);
 			// the leaf kernel is the dominant one: time it alone (the last band's launch when there are several)
 			if(hook && hook->start && last) (void) hipEventRecord(hook->start, stream);
-			hipLaunchKernelGGL(skr_leaf_kernel, dim3(256u * 3u), dim3(256), lds_leaf, stream, p); // every workgroup resident
+			if(tris) hipLaunchKernelGGL(skr_leaf_kernel<true>, dim3(256u * 3u), dim3(256), lds_leaf, stream, p); // every workgroup resident
+			else hipLaunchKernelGGL(skr_leaf_kernel<false>, dim3(256u * 3u), dim3(256), lds_leaf, stream, p);
 			if(hook && hook->stop && last) (void) hipEventRecord(hook->stop, stream);
 			hipLaunchKernelGGL(skr_finalize_kernel, dim3((unsigned) ((pixels + 255) / 256)), dim3(256), 0, stream, p);
 			e = hipGetLastError();
