@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 // Same values, same order of every float sum: the image is bit-identical to the other paths.
 // =====================================================================================
 namespace {
-constexpr int LEAF_S1 = 512, LEAF_AW = 32, LEAF_Q2 = 192;                       // leaf slots of a window, parents per window, leaf-hit ring
+constexpr int LEAF_S1 = 384, LEAF_AW = 24, LEAF_Q2 = 128;                       // leaf slots of a window, parents per window, leaf-hit ring
 constexpr int LEAF_WAVE_FLOATS = LEAF_S1 * 3 + LEAF_AW + LEAF_Q2 * QF;
 SKR_DEV uint32_t *p1_counter(const RenderParams &p, uint32_t region) { return p.qctr + SKR_PULL_STRIDE * (1u + SKR_PULL_QUEUES + region); }
 SKR_DEV uint32_t *p1_taken(const RenderParams &p, uint32_t region) { return p.qctr + SKR_PULL_STRIDE * (1u + SKR_PULL_QUEUES + SKR_P1_REGIONS + region); } // units handed out
@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(256) void skr_level1_kernel(const RenderParams p)
 }
 
 template <bool TRIS>
-__global__ __launch_bounds__(256, 3) void skr_leaf_kernel(const RenderParams p)
+__global__ __launch_bounds__(256, 4) void skr_leaf_kernel(const RenderParams p)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
@@ -1363,7 +1363,7 @@ __global__ __launch_bounds__(256, 3) void skr_leaf_kernel(const RenderParams p)
 	w.s0_max = 0;
 	w.s1_max = LEAF_S1;
 	w.sbase1 = 0;
-	w.q2_two_step = false;
+	w.q2_two_step = LEAF_Q2 < 63 + 128;
 	w.par0_max = 0;
 	w.aw_max = LEAF_AW;
 	w.act_max = 64;
@@ -1680,8 +1680,8 @@ hipError_t skr_launch_levels(const RenderParams &p_in, hipStream_t stream, const
 			else hipLaunchKernelGGL(skr_level1_kernel<false>, grid1, dim3(256), lds_scene, stream, p);
 			// the leaf kernel is the dominant one: time it alone (the last band's launch when there are several)
 			if(hook && hook->start && last) (void) hipEventRecord(hook->start, stream);
-			if(tris) hipLaunchKernelGGL(skr_leaf_kernel<true>, dim3(256u * 3u), dim3(256), lds_leaf, stream, p); // every workgroup resident
-			else hipLaunchKernelGGL(skr_leaf_kernel<false>, dim3(256u * 3u), dim3(256), lds_leaf, stream, p);
+			if(tris) hipLaunchKernelGGL(skr_leaf_kernel<true>, dim3(256u * 4u), dim3(256), lds_leaf, stream, p); // every workgroup resident
+			else hipLaunchKernelGGL(skr_leaf_kernel<false>, dim3(256u * 4u), dim3(256), lds_leaf, stream, p);
 			if(hook && hook->stop && last) (void) hipEventRecord(hook->stop, stream);
 			hipLaunchKernelGGL(skr_finalize_kernel, dim3((unsigned) ((pixels + 255) / 256)), dim3(256), 0, stream, p);
 			e = hipGetLastError();
