@@ -717,7 +717,7 @@ SKR_DEV f3 shade_tile_sample(const Wave &w, bool valid, f3 o, f3 d, uint32_t pix
 
 // One workgroup = 4 independent waves; wave w of block (bx, by) owns the 8x8 pixel tile
 // (2*bx + (w&1), 2*by + (w>>1)).  Dynamic LDS: scene SoA (shared, staged once) | 4 wave areas.
-template <int DEPTH, int OCC>
+template <int DEPTH, int OCC, bool TRIS = true> // TRIS = false: no triangles in the scene, the walk is compiled out
 __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 	using C = Cfg<OCC>;
 	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * C::WAVE_LDS_FLOATS;
 	Wave w;
-	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
+	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
 	w.p = &p;
 	w.slots = wbase;
 	w.lane = lane;
@@ -937,7 +937,8 @@ SKR_DEV void emit_sample(const RenderParams &p, uint32_t out_pix, f3 c)
 
 } // namespace
 
-// One workgroup = a 16x16 pixel block, one lane per pixel.
+// One workgroup = a 16x16 pixel block, one lane per pixel.  TRIS = false: no triangles in the scene, the walk is compiled out.
+template <bool TRIS>
 __global__ __launch_bounds__(256) void skr_primary_kernel(const RenderParams p)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -956,7 +957,7 @@ __global__ __launch_bounds__(256) void skr_primary_kernel(const RenderParams p)
 	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
 	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	__syncthreads();
-	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
+	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
 
 	const int wave = tid >> 6, lane = tid & 63;
 	const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
@@ -1538,13 +1539,13 @@ bool skr_wave_supported(const RenderParams &p)
 	return p.max_depth >= 1 && p.max_depth <= 3 && p.num_path_traces <= GILLUM_MAX && p.n_spheres < 65536;
 }
 
-template <int D, int OCC>
+template <int D, int OCC, bool TRIS = true>
 static hipError_t launch_wave_depth(const RenderParams &p, dim3 grid, size_t lds, hipStream_t stream)
 {
 	// > 64 KiB of dynamic LDS per workgroup has to be opted into
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(skr_wave_kernel<D, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(skr_wave_kernel<D, OCC, TRIS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 	if(e != hipSuccess) return e;
-	hipLaunchKernelGGL((skr_wave_kernel<D, OCC>), grid, dim3(256), lds, stream, p);
+	hipLaunchKernelGGL((skr_wave_kernel<D, OCC, TRIS>), grid, dim3(256), lds, stream, p);
 	return hipGetLastError();
 }
 
@@ -1579,7 +1580,7 @@ hipError_t skr_launch_wave(const RenderParams &p_in, hipStream_t stream)
 	// hit that would: every depth is then the depth-1 instance
 	switch((p.monte_carlo && p.n_spheres > 0) ? p.max_depth : 1)
 	{
-		case 1: return launch_wave_depth<1, 3>(p, grid, lds, stream);
+		case 1: return p.n_tris > 0 ? launch_wave_depth<1, 3, true>(p, grid, lds, stream) : launch_wave_depth<1, 3, false>(p, grid, lds, stream);
 		case 2: return occ3 ? launch_wave_depth<2, 3>(p, grid, lds, stream) : launch_wave_depth<2, 2>(p, grid, lds, stream);
 		case 3: return occ3 ? launch_wave_depth<3, 3>(p, grid, lds, stream) : launch_wave_depth<3, 2>(p, grid, lds, stream);
 		default: return hipErrorInvalidValue;
@@ -1674,7 +1675,8 @@ hipError_t skr_launch_levels(const RenderParams &p_in, hipStream_t stream, const
 			const bool last = s == nsamp - 1 && row0 + band >= p.out_rows;
 			e = hipMemsetAsync(p.qctr, 0, (SKR_PULL_QUEUES + 1 + 2 * SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t), stream);
 			if(e != hipSuccess) return e;
-			hipLaunchKernelGGL(skr_primary_kernel, dim3((p.width + 15) / 16, (p.band_rows + 15) / 16), dim3(256), lds_scene, stream, p);
+			if(tris) hipLaunchKernelGGL(skr_primary_kernel<true>, dim3((p.width + 15) / 16, (p.band_rows + 15) / 16), dim3(256), lds_scene, stream, p);
+			else hipLaunchKernelGGL(skr_primary_kernel<false>, dim3((p.width + 15) / 16, (p.band_rows + 15) / 16), dim3(256), lds_scene, stream, p);
 			const dim3 grid1((unsigned) ((levels_pairs_max(p, p.band_rows) + 255) / 256));
 			if(tris) hipLaunchKernelGGL(skr_level1_kernel<true>, grid1, dim3(256), lds_scene, stream, p);
 			else hipLaunchKernelGGL(skr_level1_kernel<false>, grid1, dim3(256), lds_scene, stream, p);
@@ -1722,7 +1724,8 @@ hipError_t skr_launch_queue(const RenderParams &p_in, hipStream_t stream, const 
 		p.aa_index = (uint32_t) s;
 		hipError_t e = hipMemsetAsync(p.qctr, 0, (SKR_PULL_QUEUES + 1) * SKR_PULL_STRIDE * sizeof(uint32_t), stream);
 		if(e != hipSuccess) return e;
-		hipLaunchKernelGGL(skr_primary_kernel, grid1, dim3(256), lds1, stream, p);
+		if(p.n_tris > 0) hipLaunchKernelGGL(skr_primary_kernel<true>, grid1, dim3(256), lds1, stream, p);
+		else hipLaunchKernelGGL(skr_primary_kernel<false>, grid1, dim3(256), lds1, stream, p);
 		e = hipGetLastError();
 		if(e != hipSuccess) return e;
 		// the GI kernel is the dominant one: time it alone (last sample's launch when there are several)
