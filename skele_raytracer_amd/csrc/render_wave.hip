@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(256) void skr_primary_kernel(const RenderParams p)
 }
 
 // Persistent waves: pull groups of parents, stream their trees, finish their pixels.
-template <int DEPTH, int OCC>
+template <int DEPTH, int OCC, bool TRIS> // TRIS = false: no triangles in the scene, the walk is compiled out
 __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 	using C = Cfg<OCC, true>;
 	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * C::WAVE_LDS_FLOATS;
 	Wave w;
-	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
+	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
 	w.p = &p;
 	w.slots = wbase;
 	w.lane = lane;
@@ -1630,15 +1630,15 @@ static uint64_t levels_tasks_max(const RenderParams &p, uint32_t rows)
 
 // Default for --gillum at depth 3 on sphere scenes (measured against the parent-queue pipeline, 1080p: headline 2.54 ->
 // 2.42 ms, no shadows 1.98 -> 1.85, bear 1.02 -> 0.63, gillum 4 / 8 / 64 / 255: -37 / -16 / -17 / -46 %, one rank's 1/8 frame
-// 0.46 -> 0.41); triangle scenes stay on the parent-queue pipeline (test.scn: 1.5 vs 2.8 ms — their rounds are long
-// and few).  SKR_PIPELINE=levels | queue | mega forces one.
+// 0.46 -> 0.41); scenes with triangle meshes (more than 64 triangles) stay on the parent-queue pipeline (test.scn: 1.5 vs 2.8 ms —
+// their rounds are long and few).  SKR_PIPELINE=levels | queue | mega forces one.
 bool skr_levels_selected(const RenderParams &p)
 {
 	const char *e = getenv("SKR_PIPELINE");
 	const bool forced = e && !strcmp(e, "levels");
 	if(e && !forced) return false;
 	if(!(skr_wave_supported(p) && p.monte_carlo && p.n_spheres > 0 && p.max_depth == 3 && p.num_path_traces > 0 && p.num_path_traces <= 255)) return false;
-	if(p.n_tris > 0 && !forced) return false;
+	if(p.n_tris > 64 && !forced) return false; // a handful of triangles costs nothing (spheres1: 1.31 -> 1.18 ms); meshes stay on the parent queue
 	return levels_tasks_max(p, levels_band_rows(p)) * 3 < (1ull << 30);
 }
 
@@ -1699,14 +1699,19 @@ hipError_t skr_launch_levels(const RenderParams &p_in, hipStream_t stream, const
 	return hipSuccess;
 }
 
+template <int D, int OCC, bool TRIS>
+static hipError_t launch_gi_t(const RenderParams &p, size_t lds, hipStream_t stream)
+{
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(skr_gi_kernel<D, OCC, TRIS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+	if(e != hipSuccess) return e;
+	const dim3 grid(256u * (uint32_t) OCC); // every workgroup resident: 256 CUs x OCC workgroups of 4 waves
+	hipLaunchKernelGGL((skr_gi_kernel<D, OCC, TRIS>), grid, dim3(256), lds, stream, p);
+	return hipGetLastError();
+}
 template <int D, int OCC>
 static hipError_t launch_gi(const RenderParams &p, size_t lds, hipStream_t stream)
 {
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(skr_gi_kernel<D, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-	if(e != hipSuccess) return e;
-	const dim3 grid(256u * (uint32_t) OCC); // every workgroup resident: 256 CUs x OCC workgroups of 4 waves
-	hipLaunchKernelGGL((skr_gi_kernel<D, OCC>), grid, dim3(256), lds, stream, p);
-	return hipGetLastError();
+	return p.n_tris > 0 ? launch_gi_t<D, OCC, true>(p, lds, stream) : launch_gi_t<D, OCC, false>(p, lds, stream);
 }
 
 hipError_t skr_launch_queue(const RenderParams &p_in, hipStream_t stream, const SkrTimingHook *hook)
