@@ -218,7 +218,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; FETCH doubled per the gfx950 note)" if traffic else None,
-                         "kernel": {"level_queues_v4": "skr_leaf_kernel", "parent_queue_v3": "skr_gi_kernel<3, 3, false>", "wave_streaming_v2": "skr_wave_kernel<3, 3>"}.get(r.kernel_variant(), "skr_render_kernel<3>"), "kernel_ms": kernel_ms, "render_ms": pipeline_ms, "algorithmic_bytes_per_launch": launch_bytes, "frame_bytes": frame_bytes, "queued_parents": n_parents, "queued_level1_hits": level1,
+                         "kernel": {"level_queues_v4": "skr_leaf_kernel<false>", "parent_queue_v3": "skr_gi_kernel<3, 3, false>", "wave_streaming_v2": "skr_wave_kernel<3, 3>"}.get(r.kernel_variant(), "skr_render_kernel<3>"), "kernel_ms": kernel_ms, "render_ms": pipeline_ms, "algorithmic_bytes_per_launch": launch_bytes, "frame_bytes": frame_bytes, "queued_parents": n_parents, "queued_level1_hits": level1,
                          "note": "algorithmic HBM bytes of the dominant kernel: the level-1 hit records it reads (64 B) and the slots it writes (12 B) + ~1 KB of scene; this path is FP32-VALU bound, see roofline_valu"},
             "roofline_valu": {"bound": "fp32_valu", "achieved": alg_flop / (kernel_ms * 1e-3) / 1e12 / world * 1.0,
                               "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": alg_flop / (kernel_ms * 1e-3) / 1e12 / world / VALU_PEAK_TFLOPS,
