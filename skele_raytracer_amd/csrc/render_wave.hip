@@ -56,6 +56,9 @@ struct Cfg {
 	// level-1 parents of the current group live in LDS (8 dwords each), not in registers: they are only
 	// touched once per round, and holding them in VGPRs through the leaf phases cost occupancy
 	static constexpr int WAVE_LDS_FLOATS = SLOT_FLOATS + (Q1_CAP + Q2_CAP) * QF + PAR0_MAX * 8;
+	// the depth-1 instance (no --gillum tree) only ever touches the u8 tile staging area: 2 KB per wave instead of
+	// 13 KB, so that LDS no longer caps it at 3 waves per SIMD
+	static constexpr int DEPTH1_WAVE_FLOATS = REGION0_FLOATS + 64 + PAR0_MAX * 3 + 64;
 	static_assert(REGION1_FLOATS >= 64 + 16 * 3 + 48, "aliases must fit");
 };
 constexpr int GILLUM_MAX = 256; // child index is 8 bits in HitRec.ids; Cfg<2>::S0_MAX
@@ -738,7 +741,7 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 
 	const int wave = tid >> 6, lane = tid & 63;
 	using C = Cfg<OCC>;
-	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * C::WAVE_LDS_FLOATS;
+	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * (DEPTH == 1 ? C::DEPTH1_WAVE_FLOATS : C::WAVE_LDS_FLOATS);
 	Wave w;
 	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
 	w.p = &p;
@@ -1580,7 +1583,13 @@ hipError_t skr_launch_wave(const RenderParams &p_in, hipStream_t stream)
 	// hit that would: every depth is then the depth-1 instance
 	switch((p.monte_carlo && p.n_spheres > 0) ? p.max_depth : 1)
 	{
-		case 1: return p.n_tris > 0 ? launch_wave_depth<1, 3, true>(p, grid, lds, stream) : launch_wave_depth<1, 3, false>(p, grid, lds, stream);
+		case 1:
+		{
+			const size_t lds1 = ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + (size_t) 4 * Cfg<3>::DEPTH1_WAVE_FLOATS * sizeof(float);
+			// measured: config 2 (spheres2 --jsample 5) 1.83 -> 1.63 ms with the small allocation (4+ waves per SIMD), but the
+			// triangle walk of dragon 1.25 -> 1.42 ms (its scalar loads thrash with more waves resident): meshes keep the large one
+			return p.n_tris > 0 ? launch_wave_depth<1, 3, true>(p, grid, lds, stream) : launch_wave_depth<1, 3, false>(p, grid, lds1, stream);
+		}
 		case 2: return occ3 ? launch_wave_depth<2, 3>(p, grid, lds, stream) : launch_wave_depth<2, 2>(p, grid, lds, stream);
 		case 3: return occ3 ? launch_wave_depth<3, 3>(p, grid, lds, stream) : launch_wave_depth<3, 2>(p, grid, lds, stream);
 		default: return hipErrorInvalidValue;
