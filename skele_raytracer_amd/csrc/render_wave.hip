@@ -1587,7 +1587,7 @@ hipError_t skr_launch_wave(const RenderParams &p_in, hipStream_t stream)
 		{
 			const size_t lds1 = ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + (size_t) 4 * Cfg<3>::DEPTH1_WAVE_FLOATS * sizeof(float);
 			// measured: config 2 (spheres2 --jsample 5) 1.83 -> 1.63 ms with the small allocation (4+ waves per SIMD), but the
-			// triangle walk of dragon 1.25 -> 1.42 ms (its scalar loads thrash with more waves resident): meshes keep the large one
+			// triangle walk of dragon 1.28 -> 1.36 ms (1 / 2 / 3 / 4+ waves per SIMD: 2.05 / 1.31 / 1.28 / 1.36 ms): meshes keep the large one
 			return p.n_tris > 0 ? launch_wave_depth<1, 3, true>(p, grid, lds, stream) : launch_wave_depth<1, 3, false>(p, grid, lds1, stream);
 		}
 		case 2: return occ3 ? launch_wave_depth<2, 3>(p, grid, lds, stream) : launch_wave_depth<2, 2>(p, grid, lds, stream);
