@@ -1208,6 +1208,7 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 namespace {
 constexpr int LEAF_S1 = 384, LEAF_AW = 24, LEAF_Q2 = 128;                       // leaf slots of a window, parents per window, leaf-hit ring
 constexpr int LEAF_WAVE_FLOATS = LEAF_S1 * 3 + LEAF_AW + LEAF_Q2 * QF;
+static_assert(SKR_P1_REGIONS == 64u, "the leaf kernel looks at one region per lane when its own runs dry");
 SKR_DEV uint32_t *p1_counter(const RenderParams &p, uint32_t region) { return p.qctr + SKR_PULL_STRIDE * (1u + SKR_PULL_QUEUES + region); }
 SKR_DEV uint32_t *p1_taken(const RenderParams &p, uint32_t region) { return p.qctr + SKR_PULL_STRIDE * (1u + SKR_PULL_QUEUES + SKR_P1_REGIONS + region); } // units handed out
 } // namespace
@@ -1349,7 +1350,8 @@ __global__ __launch_bounds__(256, 4) void skr_leaf_kernel(const RenderParams p)
 	__syncthreads(); // the only workgroup barrier
 	const int wave = tid >> 6, lane = tid & 63;
 	const uint32_t g = (uint32_t) blockIdx.x * 4u + (uint32_t) wave;
-	uint32_t region = g & (SKR_P1_REGIONS - 1u), dry = 0;
+	uint32_t region = g & (SKR_P1_REGIONS - 1u);
+	unsigned long long dead = 0; // regions this wave has seen exhausted
 	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * LEAF_WAVE_FLOATS;
 	Wave w;
 	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
@@ -1380,17 +1382,31 @@ __global__ __launch_bounds__(256, 4) void skr_leaf_kernel(const RenderParams p)
 	for(;;)
 	{
 		uint32_t first = 0, cnt = 0;
+		bool got = false;
 		for(;;)
-		{ // pull the next unit (wave-uniform): this region's, or the next region's once this one is exhausted
+		{ // pull the next unit (wave-uniform): this region's, or another region's once this one is exhausted
 			cnt = *p1_counter(p, region);
 			uint32_t k = 0;
 			if(lane == 0) k = atomicAdd(p1_taken(p, region), 1u);
 			first = (uint32_t) __builtin_amdgcn_readfirstlane((int) k) * 64u;
-			if(first < cnt) break;
-			region = (region + 1u) & (SKR_P1_REGIONS - 1u);
-			if(++dry == SKR_P1_REGIONS) break;
+			if(first < cnt)
+			{
+				got = true;
+				break;
+			}
+			// This region is exhausted.  Walking the other 63 one atomic at a time cost every wave ~64 round trips at
+			// the end (a third of a 1/8-frame kernel): instead lane r looks at region r — plain loads; a stale "taken"
+			// can only be too low, which costs one failed atomic and a bit in `dead` — and the wave goes to the first
+			// region after its own that still has units.
+			dead |= 1ull << region;
+			const uint32_t c_r = *p1_counter(p, (uint32_t) lane), t_r = *p1_taken(p, (uint32_t) lane);
+			const bool alive = !((dead >> lane) & 1ull) && (unsigned long long) t_r * 64ull < (unsigned long long) c_r;
+			const unsigned long long live = __ballot(alive);
+			if(live == 0ull) break;
+			const unsigned long long after = region == 63u ? 0ull : (live >> (region + 1u)) << (region + 1u); // regions above this one
+			region = (uint32_t) __builtin_ctzll(after ? after : live);
 		}
-		if(dry == SKR_P1_REGIONS) break;
+		if(!got) break;
 		const float4 *reg = p.p1 + (size_t) region * p.p1_region_cap * 4;
 		const int m = (int) (cnt - first < 64u ? cnt - first : 64u);
 		HitRec h;
