@@ -115,8 +115,8 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	if(nch) memcpy(&blob[r->off_chunks], scene->tri_chunks.data(), nch * 16);
 	hipError_t e = hipMalloc((void **) &r->d_blob, blob.size() * 16);
 	if(e == hipSuccess) e = hipMemcpy(r->d_blob, blob.data(), blob.size() * 16, hipMemcpyHostToDevice);
-	if(e == hipSuccess) e = hipMalloc((void **) &r->d_counters, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long) + (SKR_PULL_QUEUES + 1 + 2 * SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t));
-	if(e == hipSuccess) e = hipMemset(r->d_counters, 0, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long) + (SKR_PULL_QUEUES + 1 + 2 * SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t));
+	if(e == hipSuccess) e = hipMalloc((void **) &r->d_counters, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long) + (SKR_PULL_QUEUES + 2 + 2 * SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t));
+	if(e == hipSuccess) e = hipMemset(r->d_counters, 0, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long) + (SKR_PULL_QUEUES + 2 + 2 * SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t));
 	if(e != hipSuccess)
 	{
 		skr_set_error("scene upload failed: %s", hipGetErrorString(e));

@@ -1205,12 +1205,22 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 //   skr_finalize_kernel  one lane per parent: the N slots strictly in child order, (direct/pi + 2 indirect) * kd
 // Same values, same order of every float sum: the image is bit-identical to the other paths.
 // =====================================================================================
+#if defined(SKR_STAMPS) && SKR_STAMPS
+static __device__ unsigned long long skr_leaf_times[5 * 4096];
+extern "C" void skr_leaf_times_read(unsigned long long *out)
+{
+	(void) hipDeviceSynchronize();
+	(void) hipMemcpyFromSymbol(out, HIP_SYMBOL(skr_leaf_times), sizeof(unsigned long long) * 5 * 4096);
+}
+#endif
+
 namespace {
 constexpr int LEAF_S1 = 384, LEAF_AW = 24, LEAF_Q2 = 128;                       // leaf slots of a window, parents per window, leaf-hit ring
 constexpr int LEAF_WAVE_FLOATS = LEAF_S1 * 3 + LEAF_AW + LEAF_Q2 * QF;
 static_assert(SKR_P1_REGIONS == 64u, "the leaf kernel looks at one region per lane when its own runs dry");
 SKR_DEV uint32_t *p1_counter(const RenderParams &p, uint32_t region) { return p.qctr + SKR_PULL_STRIDE * (1u + SKR_PULL_QUEUES + region); }
 SKR_DEV uint32_t *p1_taken(const RenderParams &p, uint32_t region) { return p.qctr + SKR_PULL_STRIDE * (1u + SKR_PULL_QUEUES + SKR_P1_REGIONS + region); } // units handed out
+SKR_DEV unsigned long long *p1_dead_mask(const RenderParams &p) { return reinterpret_cast<unsigned long long *>(p.qctr + SKR_PULL_STRIDE * (1u + SKR_PULL_QUEUES + 2u * SKR_P1_REGIONS)); } // regions seen exhausted
 } // namespace
 
 // TRIS = false: the scene has no triangles (the launcher's default case) and the walk is compiled out.
@@ -1352,6 +1362,11 @@ __global__ __launch_bounds__(256, 4) void skr_leaf_kernel(const RenderParams p)
 	const uint32_t g = (uint32_t) blockIdx.x * 4u + (uint32_t) wave;
 	uint32_t region = g & (SKR_P1_REGIONS - 1u);
 	unsigned long long dead = 0; // regions this wave has seen exhausted
+#if defined(SKR_STAMPS) && SKR_STAMPS
+	const unsigned long long wt_start = wall_clock64(); // 100 MHz, one clock for the whole device (the cycle counter is per XCD)
+	unsigned long long wt_first = 0, wt_last = 0;
+	uint32_t wt_units = 0;
+#endif
 	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * LEAF_WAVE_FLOATS;
 	Wave w;
 	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
@@ -1386,6 +1401,8 @@ __global__ __launch_bounds__(256, 4) void skr_leaf_kernel(const RenderParams p)
 		for(;;)
 		{ // pull the next unit (wave-uniform): this region's, or another region's once this one is exhausted
 			cnt = *p1_counter(p, region);
+			// (16-record pulls for a region's last quarter — units differ 2-3x in cost, and a wave's last whole unit sets
+			// the kernel's tail — were measured slower, 1.58 -> 1.67 ms: a small unit costs far more than its share)
 			uint32_t k = 0;
 			if(lane == 0) k = atomicAdd(p1_taken(p, region), 1u);
 			first = (uint32_t) __builtin_amdgcn_readfirstlane((int) k) * 64u;
@@ -1394,14 +1411,16 @@ __global__ __launch_bounds__(256, 4) void skr_leaf_kernel(const RenderParams p)
 				got = true;
 				break;
 			}
-			// This region is exhausted.  Walking the other 63 one atomic at a time cost every wave ~64 round trips at
-			// the end (a third of a 1/8-frame kernel): instead lane r looks at region r — plain loads; a stale "taken"
-			// can only be too low, which costs one failed atomic and a bit in `dead` — and the wave goes to the first
-			// region after its own that still has units.
-			dead |= 1ull << region;
-			const uint32_t c_r = *p1_counter(p, (uint32_t) lane), t_r = *p1_taken(p, (uint32_t) lane);
-			const bool alive = !((dead >> lane) & 1ull) && (unsigned long long) t_r * 64ull < (unsigned long long) c_r;
-			const unsigned long long live = __ballot(alive);
+			// This region is exhausted.  Walking the other 63 one atomic at a time cost every wave up to 64 round trips at
+			// the end (per-wave timeline: 90 .. 270 us between the last unit and the exit; plain loads of the other
+			// regions' counters are too stale to help).  Instead the exhausted regions are published in one 64-bit mask:
+			// the atomic OR that adds this region returns everybody else's findings, and the wave goes to the first
+			// region after its own that nobody has seen dry — or leaves when there is none.
+			unsigned long long seen = 0;
+			if(lane == 0) seen = atomicOr(p1_dead_mask(p), 1ull << region);
+			const uint32_t lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) seen), hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (seen >> 32));
+			dead |= ((unsigned long long) hi << 32 | lo) | (1ull << region);
+			const unsigned long long live = ~dead;
 			if(live == 0ull) break;
 			const unsigned long long after = region == 63u ? 0ull : (live >> (region + 1u)) << (region + 1u); // regions above this one
 			region = (uint32_t) __builtin_ctzll(after ? after : live);
@@ -1432,8 +1451,25 @@ __global__ __launch_bounds__(256, 4) void skr_leaf_kernel(const RenderParams p)
 			h.slot = SLOT_GLOBAL | (int) (__float_as_uint(n3.x) * 3u);
 		}
 		STAMP(0);
+#if defined(SKR_STAMPS) && SKR_STAMPS
+		if(wt_units == 0) wt_first = wall_clock64();
+#endif
 		expand_level1_hits(w, m, h, co0, pixel, q2, cn STAMP_PASS);
+#if defined(SKR_STAMPS) && SKR_STAMPS
+		wt_units++;
+		wt_last = wall_clock64();
+#endif
 	}
+#if defined(SKR_STAMPS) && SKR_STAMPS
+	if(lane == 0 && g < 4096u)
+	{ // per-wave timeline (tools/leaf_timeline.py): kernel entry, first unit in hand, last unit done, exit, units
+		skr_leaf_times[5 * g] = wt_start;
+		skr_leaf_times[5 * g + 1] = wt_first;
+		skr_leaf_times[5 * g + 2] = wt_last;
+		skr_leaf_times[5 * g + 3] = wall_clock64();
+		skr_leaf_times[5 * g + 4] = wt_units;
+	}
+#endif
 #if defined(SKR_STAMPS) && SKR_STAMPS
 	if(p.counters && lane == 0)
 		for(int k = 0; k < 8; k++) atomicAdd(&p.counters[4u * SKR_COUNTER_SHARDS + k], st_acc[k]);
@@ -1698,7 +1734,7 @@ hipError_t skr_launch_levels(const RenderParams &p_in, hipStream_t stream, const
 			p.band_rows = p.out_rows - row0 < band ? p.out_rows - row0 : band;
 			const uint64_t pixels = (uint64_t) p.width * p.band_rows;
 			const bool last = s == nsamp - 1 && row0 + band >= p.out_rows;
-			e = hipMemsetAsync(p.qctr, 0, (SKR_PULL_QUEUES + 1 + 2 * SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t), stream);
+			e = hipMemsetAsync(p.qctr, 0, (SKR_PULL_QUEUES + 2 + 2 * SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t), stream);
 			if(e != hipSuccess) return e;
 			if(tris) hipLaunchKernelGGL(skr_primary_kernel<true>, dim3((p.width + 15) / 16, (p.band_rows + 15) / 16), dim3(256), lds_scene, stream, p);
 			else hipLaunchKernelGGL(skr_primary_kernel<false>, dim3((p.width + 15) / 16, (p.band_rows + 15) / 16), dim3(256), lds_scene, stream, p);
