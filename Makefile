@@ -10,18 +10,30 @@ LIBDIR  := skele_raytracer_amd/lib
 # float divide/sqrt stay correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
             -fno-fast-math -Wall -Wno-unused-function -Iinclude
-KERNEL_SRCS := $(CSRC)/render_kernel.hip $(CSRC)/render_wave.hip
+KERNEL_SRCS := $(CSRC)/render_kernel.hip $(CSRC)/render_wave.hip $(CSRC)/render_nodes.hip
 HOST_SRCS   := $(CSRC)/api.cpp $(CSRC)/scene_host.cpp
-HDRS        := include/skr.h $(CSRC)/device_math.h $(CSRC)/shade_common.h $(CSRC)/render_params.h $(CSRC)/scene_host.h $(CSRC)/tri_chunks.h
+HDRS        := include/skr.h $(CSRC)/device_math.h $(CSRC)/shade_common.h $(CSRC)/render_params.h $(CSRC)/scene_host.h $(CSRC)/tri_chunks.h $(CSRC)/wave_common.h
 
 all: lib cli oracle
 
 lib: $(LIBDIR)/libskr.so
 cli: bin/raytracer
 
-$(LIBDIR)/libskr.so: $(KERNEL_SRCS) $(HOST_SRCS) $(HDRS)
+OBJDIR := build/obj
+OBJS   := $(OBJDIR)/render_kernel.o $(OBJDIR)/render_wave.o $(OBJDIR)/render_nodes.o $(OBJDIR)/api.o $(OBJDIR)/scene_host.o
+
+# one object per translation unit (the three kernel files take a minute each: `make -j4 lib`)
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(EXTRA) -c -o $@ $<
+
+$(OBJDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(EXTRA) -c -o $@ -x hip $<
+
+$(LIBDIR)/libskr.so: $(OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(KERNEL_SRCS) -x hip $(HOST_SRCS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
 bin/raytracer: $(CSRC)/raytracer_main.cpp include/skr.h $(LIBDIR)/libskr.so
 	@mkdir -p bin
@@ -34,6 +46,7 @@ asm: $(KERNEL_SRCS) $(HDRS)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S -o build/render_kernel.s $(CSRC)/render_kernel.hip -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt
 	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S -o build/render_wave.s $(CSRC)/render_wave.hip -Rpass-analysis=kernel-resource-usage 2>> build/resource_usage.txt
+	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S -o build/render_nodes.s $(CSRC)/render_nodes.hip -Rpass-analysis=kernel-resource-usage 2>> build/resource_usage.txt
 
 clean:
 	rm -rf $(LIBDIR) bin build

@@ -18,6 +18,8 @@ size_t skr_render_lds_bytes(const RenderParams &p);
 bool skr_queue_selected(const RenderParams &p);
 void skr_queue_scratch_bytes(const RenderParams &p, size_t *parent_bytes, size_t *acc_bytes);
 bool skr_levels_scratch_bytes(RenderParams &p, size_t *p1_bytes, size_t *slot1_bytes);
+bool skr_nodes_selected(const RenderParams &p);
+size_t skr_nodes_scratch_bytes(const RenderParams &p);
 
 static thread_local const char *g_variant = "none";
 
@@ -45,6 +47,8 @@ struct skr_renderer {
 	void *d_parents = nullptr;
 	void *d_levels = nullptr; // level-queue pipeline: level-1 hit records + level-1 slots
 	size_t levels_cap = 0;
+	void *d_nodes = nullptr;  // node pipeline: every table of one band (render_nodes.hip NodePlan)
+	size_t nodes_cap = 0;
 	size_t parents_cap = 0;
 	float *d_acc = nullptr;
 	size_t acc_cap = 0;
@@ -137,6 +141,7 @@ void skr_renderer_destroy(skr_renderer *r)
 	if(r->d_counters) (void) hipFree(r->d_counters);
 	if(r->d_parents) (void) hipFree(r->d_parents);
 	if(r->d_levels) (void) hipFree(r->d_levels);
+	if(r->d_nodes) (void) hipFree(r->d_nodes);
 	if(r->d_acc) (void) hipFree(r->d_acc);
 	for(SkrTimingHook &h : r->timed) { (void) hipEventDestroy(h.start); (void) hipEventDestroy(h.stop); }
 	for(SkrTimingHook &h : r->free_pairs) { (void) hipEventDestroy(h.start); (void) hipEventDestroy(h.stop); }
@@ -163,25 +168,10 @@ static int check_options(const skr_options *opt)
 		skr_set_error("depth takes a positive int after flag for the max depth");
 		return SKR_ERR_ARG;
 	}
-	if(opt->max_depth > 6)
-	{
-		skr_set_error("--depth %d: the GPU path instantiates depths 1..6", opt->max_depth);
-		return SKR_ERR_UNSUPPORTED;
-	}
 	if(opt->grid_size < 0 || opt->grid_size > 1024 || opt->num_path_traces < 0 || opt->num_path_traces > 32767)
 	{
 		skr_set_error("jsample/gillum out of range (%d, %d)", opt->grid_size, opt->num_path_traces);
 		return SKR_ERR_ARG;
-	}
-	if(opt->monte_carlo)
-	{ // tree node ids are 32-bit RNG counter words: need N^(depth-1) < 2^32
-		double nodes = 1;
-		for(int k = 1; k < opt->max_depth; k++) nodes = nodes * (double) opt->num_path_traces + 1;
-		if(nodes >= 4294967296.0)
-		{
-			skr_set_error("gillum %d at depth %d needs more than 2^32 tree nodes per sample", opt->num_path_traces, opt->max_depth);
-			return SKR_ERR_UNSUPPORTED;
-		}
 	}
 	return SKR_OK;
 }
@@ -249,13 +239,58 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.grid_size = opt->grid_size;
 	p.max_depth = opt->max_depth;
 	p.use_shadows = opt->use_shadows ? 1 : 0;
+	// shade() only recurses under --gillum and only below a sphere hit (raytrace.h:208-218), and with N = 0 there is no
+	// child to recurse into: every --depth is then the depth-1 image
+	if(!p.monte_carlo || p.n_spheres == 0 || p.num_path_traces == 0) p.max_depth = 1;
+	if(p.max_depth > 1)
+	{ // tree node ids are 32-bit RNG counter words: need N^(depth-1) < 2^32
+		double nodes = 1;
+		for(int k = 1; k < p.max_depth && nodes < 4294967296.0; k++) nodes = nodes * (double) p.num_path_traces + 1;
+		if(nodes >= 4294967296.0)
+		{
+			skr_set_error("gillum %d at depth %d needs more than 2^32 tree nodes per sample", p.num_path_traces, p.max_depth);
+			return SKR_ERR_UNSUPPORTED;
+		}
+	}
 	p.seed_lo = (uint32_t) opt->seed;
 	p.seed_hi = (uint32_t) (opt->seed >> 32);
 	p.rgb = d_rgb;
 	p.rgbf = d_rgbf;
 	p.counters = r->d_counters;
 	p.qctr = reinterpret_cast<uint32_t *>(r->d_counters + (size_t) SKR_COUNTER_SHARDS * 4 + 8);
-	if(skr_queue_selected(p))
+	const bool nodes_path = skr_nodes_selected(p);
+	if(!nodes_path && p.max_depth > 6)
+	{
+		skr_set_error("--depth %d with --gillum %d: the tables of one 16x16 pixel block exceed the scratch budget (SKR_LEVELS_BUDGET_MB)", p.max_depth, p.num_path_traces);
+		return SKR_ERR_UNSUPPORTED;
+	}
+	if(nodes_path)
+	{
+		const size_t need = skr_nodes_scratch_bytes(p);
+		if(need > r->nodes_cap)
+		{
+			if(r->d_nodes) SKR_HIP(hipFree(r->d_nodes));
+			r->d_nodes = nullptr;
+			r->nodes_cap = 0;
+			SKR_HIP(hipMalloc(&r->d_nodes, need));
+			r->nodes_cap = need;
+		}
+		p.node_scratch = r->d_nodes;
+		if(p.grid_size > 0)
+		{
+			const size_t need_acc = (size_t) p.width * p.out_rows * 12;
+			if(need_acc > r->acc_cap)
+			{
+				if(r->d_acc) SKR_HIP(hipFree(r->d_acc));
+				r->d_acc = nullptr;
+				r->acc_cap = 0;
+				SKR_HIP(hipMalloc((void **) &r->d_acc, need_acc));
+				r->acc_cap = need_acc;
+			}
+			p.acc = r->d_acc;
+		}
+	}
+	else if(skr_queue_selected(p))
 	{ // grow the pipeline's scratch if this launch needs more (first call / larger frame only)
 		size_t need_par = 0, need_acc = 0;
 		skr_queue_scratch_bytes(p, &need_par, &need_acc);

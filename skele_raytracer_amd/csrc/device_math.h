@@ -15,6 +15,18 @@
 
 #define SKR_DEV static __device__ __forceinline__
 
+// Diagnostic build only (-DSKR_DIAG=1): event counts, 64 shards per counter (tools/diag_counts.py).  Compiles to nothing otherwise.
+// (Not together with timing: every event is a global atomic.)
+#if defined(SKR_DIAG) && SKR_DIAG
+static __device__ unsigned long long skr_diag[32 * 64];
+#define DIAG_WAVE(i, v) do { const unsigned long long dv_ = (unsigned long long) (v); const unsigned long long dm_ = __ballot(true); if(__builtin_amdgcn_mbcnt_hi((uint32_t) (dm_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) dm_, 0u)) == 0) atomicAdd(&skr_diag[(i) * 64 + (blockIdx.x & 63)], dv_); } while(0)
+#define DIAG_LANES(i) do { const unsigned long long dl_ = __ballot(true); DIAG_WAVE(i, __popcll(dl_)); } while(0)
+#else
+#define DIAG_WAVE(i, v)
+#define DIAG_LANES(i)
+#endif
+
+
 // Correctly rounded binary32 sqrt and divide.  NOT __fsqrt_rn/__fdiv_rn: in this ROCm's
 // __clang_hip_math.h __fsqrt_rn is __ocml_native_sqrt_f32 (approximate).  Plain sqrtf and `/`
 // are IEEE-correct under -fhip-fp32-correctly-rounded-divide-sqrt (tests/test_gpu_units.py).
@@ -75,6 +87,15 @@ SKR_DEV float u31_to_unit(uint32_t w) { return (float) (w >> 1) * 4.656612873077
 // sin/cos of a binary32 angle evaluated in binary64, rounded once.
 // Its only caller, gi_direction(), is kept out of line: inlined, the binary64 polynomial constants stay
 // live across the callers' loops and cost ~40 VGPRs of pressure everywhere.
+// fma(a, b, K) with the wave-uniform constant K held in a scalar register pair: v_fma_f64 takes it as its SGPR operand.
+// (Left to itself the compiler materialises every coefficient of the two polynomials below in a VGPR pair in front of
+// a v_fmac_f64: 33 v_mov per call, a quarter of the function.)
+SKR_DEV double fma_k(double a, double b, double k)
+{
+	asm("" : "+s"(k));
+	return __builtin_fma(a, b, k);
+}
+
 SKR_DEV void sincos_spec(float phi, float &s, float &c)
 {
 	const double x = (double) phi;
@@ -84,27 +105,31 @@ SKR_DEV void sincos_spec(float phi, float &s, float &c)
 	y = fma(-kd, 0x1.0B4611A626331p-34, y);         // pi/2 low
 	const double z = y * y;
 	double ps = -1.0 / 1307674368000.0;
-	ps = fma(ps, z, 1.0 / 6227020800.0);
-	ps = fma(ps, z, -1.0 / 39916800.0);
-	ps = fma(ps, z, 1.0 / 362880.0);
-	ps = fma(ps, z, -1.0 / 5040.0);
-	ps = fma(ps, z, 1.0 / 120.0);
-	ps = fma(ps, z, -1.0 / 6.0);
+	ps = fma_k(ps, z, 1.0 / 6227020800.0);
+	ps = fma_k(ps, z, -1.0 / 39916800.0);
+	ps = fma_k(ps, z, 1.0 / 362880.0);
+	ps = fma_k(ps, z, -1.0 / 5040.0);
+	ps = fma_k(ps, z, 1.0 / 120.0);
+	ps = fma_k(ps, z, -1.0 / 6.0);
 	const double sy = fma(y * z, ps, y);
 	double pc = 1.0 / 20922789888000.0;
-	pc = fma(pc, z, -1.0 / 87178291200.0);
-	pc = fma(pc, z, 1.0 / 479001600.0);
-	pc = fma(pc, z, -1.0 / 3628800.0);
-	pc = fma(pc, z, 1.0 / 40320.0);
-	pc = fma(pc, z, -1.0 / 720.0);
-	pc = fma(pc, z, 1.0 / 24.0);
-	pc = fma(pc, z, -0.5);
-	const double cy = fma(z, pc, 1.0);
-	const int q = k & 3;
-	const double sv = (q == 0) ? sy : (q == 1) ? cy : (q == 2) ? -sy : -cy;
-	const double cv = (q == 0) ? cy : (q == 1) ? -sy : (q == 2) ? -cy : sy;
-	s = (float) sv;
-	c = (float) cv;
+	pc = fma_k(pc, z, -1.0 / 87178291200.0);
+	pc = fma_k(pc, z, 1.0 / 479001600.0);
+	pc = fma_k(pc, z, -1.0 / 3628800.0);
+	pc = fma_k(pc, z, 1.0 / 40320.0);
+	pc = fma_k(pc, z, -1.0 / 720.0);
+	pc = fma_k(pc, z, 1.0 / 24.0);
+	pc = fma_k(pc, z, -0.5);
+	const double cy = fma_k(z, pc, 1.0);
+	// quadrant k mod 4: (s, c) = (sy, cy), (cy, -sy), (-sy, -cy), (-cy, sy).  Rounding to binary32 commutes with the swap and
+	// with negation (round-to-nearest-even is symmetric), so both are done on the two rounded floats: a select and a
+	// sign-bit flip each instead of three 64-bit selects each.
+	const float sf = (float) sy, cf = (float) cy;
+	const uint32_t q = (uint32_t) k;
+	const bool swap = q & 1u;
+	const uint32_t s_sign = (q & 2u) << 30, c_sign = ((q + 1u) & 2u) << 30;
+	s = __uint_as_float(__float_as_uint(swap ? cf : sf) ^ s_sign);
+	c = __uint_as_float(__float_as_uint(swap ? sf : cf) ^ c_sign);
 }
 
 // General (non-integer exponent) branch of powf_spec: 2^(p log2 x) in binary64.  Cold for every
@@ -329,11 +354,40 @@ SKR_DEV bool bracket_decide(bool sane, float two_a, float b, float D, float &lo,
 	if(certain_reject) return false;
 	if(!certain_accept)
 	{
+		DIAG_WAVE(7, 1);
+		DIAG_LANES(3);
 		const float t = near_root_exact(two_a, b, D);
 		if(!accept_distance(t)) return false;
 		lo = hi = t;
 	}
 	return true;
+}
+
+// The any-hit form (shadow rays, utils.h:42-58) needs no bracket, only "is t2 > 1": with m = fl(-b - 2a) — one rounding
+// of an exact difference, so m = (-b - 2a)(1 + th), |th| <= 2^-24, and its sign is exact —
+//   t2 = 1 + (-b - 2a - sqrt(D)) / (2a)   (in reals, on the float values b, D, 2a)
+// is > 1 + 2^-23 (so the spec's rounded t2 is > 1) when m > a/2 and m^2 (1 - 2^-18) > D, and is <= 1 (so the spec's
+// t2 is too: rounding is monotone) when m <= 0 or m^2 (1 + 2^-18) < D; the margins leave 2^-20 relative between m
+// and sqrt(D), far more than the three binary32 roundings of the test and the binary64 roundings of the spec take.
+// Anything else — and every non-finite or tiny operand — is decided by the exact form.  No sqrt, no reciprocal.
+struct PairAny {
+	f2 two_a, quarter; // 2a and a/2 of the two rays
+	bool sane0, sane1;
+};
+SKR_DEV void pair_any_m(const PairAny &pa, f2 b, f2 &m, f2 &acc_lhs, f2 &rej_lhs)
+{
+	m = (-b) - pa.two_a;
+	const f2 m2 = m * m;
+	acc_lhs = m2 * 0x1.ffff8p-1f; // 1 - 2^-18
+	rej_lhs = m2 * 0x1.00004p+0f; // 1 + 2^-18
+}
+SKR_DEV bool any_decide(bool sane, float two_a, float quarter, float b, float D, float m, float acc_lhs, float rej_lhs)
+{
+	const bool normal = sane && (D > 1e-30f) && (b < -1e-15f) && (rej_lhs < 3.0e38f);
+	if(normal && ((m <= 0.0f) || (rej_lhs < D))) return false;
+	if(normal && (m > quarter) && (acc_lhs > D)) return true;
+	DIAG_WAVE(7, 1);
+	return accept_distance(near_root_exact(two_a, b, D));
 }
 
 SKR_DEV bool sphere_bracket(f3 o, f3 d, const RayFilt &f, float4 sph, float &lo, float &hi, float &b, float &D)

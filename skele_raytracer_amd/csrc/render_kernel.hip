@@ -188,6 +188,10 @@ bool skr_queue_selected(const RenderParams &p);
 bool skr_levels_selected(const RenderParams &p);
 hipError_t skr_launch_levels(const RenderParams &p, hipStream_t stream, const SkrTimingHook *hook);
 hipError_t skr_launch_queue(const RenderParams &p, hipStream_t stream, const SkrTimingHook *hook);
+// render_nodes.hip
+bool skr_nodes_selected(const RenderParams &p);
+size_t skr_nodes_lds_bytes(const RenderParams &p);
+hipError_t skr_launch_nodes(const RenderParams &p, hipStream_t stream, const SkrTimingHook *hook);
 
 // The wave-streaming kernel is the product path wherever it applies (depth <= 3, gillum <= 256);
 // the per-pixel kernel covers the rest (depth 4..6).  SKR_KERNEL=v1 forces the latter (A/B runs).
@@ -200,6 +204,7 @@ static bool use_wave_kernel(const RenderParams &p)
 
 size_t skr_render_lds_bytes(const RenderParams &p)
 {
+	if(skr_nodes_selected(p)) return skr_nodes_lds_bytes(p);
 	if(use_wave_kernel(p)) return skr_wave_lds_bytes(p);
 	return ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 16 * 48;
 }
@@ -213,6 +218,11 @@ static hipError_t launch_depth(const RenderParams &p, dim3 grid, size_t lds, hip
 
 hipError_t skr_launch_render(const RenderParams &p, hipStream_t stream, const char **variant, const SkrTimingHook *hook)
 {
+	if(skr_nodes_selected(p) && p.node_scratch)
+	{
+		*variant = "node_levels_v5";
+		return skr_launch_nodes(p, stream, hook);
+	}
 	if(use_wave_kernel(p))
 	{
 		if(skr_levels_selected(p) && p.parents && p.qctr && p.p1 && p.slot1)

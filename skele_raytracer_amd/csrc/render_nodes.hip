@@ -1,0 +1,933 @@
+// Node pipeline: the --gillum recursion of the reference (src/raytrace.h:107-136 called from :208-216) cut at EVERY
+// level of the tree, for any --depth >= 2 (main.cpp:318-329 accepts any positive depth).
+//
+// A *node* is a shaded sphere hit whose N children are to be traced; level 0 = the primary hits.  Rays of the last
+// level (their own children are shade(depth 0) == 0, raytrace.h:142-145) are leaves.  Kernels, in launch order:
+//
+//   skr_primary_kernel   (render_wave.hip) primary rays + direct light; every sphere hit becomes a level-0 node
+//   skr_trace_kernel     one lane per sibling pair of a node: traces the two child rays (one Philox call, one (e, c)
+//                        per sphere for both); per child one index word — r1 (miss: finalize recomputes
+//                        r1 background / pdf), IDX_BLACK (triangle, :221-224) or IDX_HIT | record — and per sphere
+//                        hit a 32-byte record appended to one of 64 regions (ballot ranks + one atomic per wave)
+//   skr_activate_kernel  (depth >= 4 only) one lane per record: shades the hit (:194-207) and writes it as a node of
+//                        the next level, which the trace kernel then expands
+//   skr_leaf_kernel2     persistent waves, one unit = 64 records of the last-but-one level, ONE LANE PER RECORD: the 64
+//                        hits are shaded full-width and stay in their lanes (origin, normal, basis, RNG key), then for
+//                        every sibling pair j the lanes trace children 2j, 2j+1 of their own node; leaf hits go through
+//                        an LDS ring and are shaded 64 at a time; contributions wait in a ring of four LDS slot
+//                        windows (one round each) until they are added, strictly in child order (:130), to the
+//                        lane's running sum.  Depth 2: the units are the level-0 nodes themselves and the pixels are
+//                        written here.
+//   skr_finalize_kernel2 one lane per node, deepest level first: the N terms in child order from the index words,
+//                        (direct/pi + 2 indirect) * kd (:213), times r1/pdf into the parent's level — or the pixel
+//
+// Every float operation and every order of summation is the reference's (DESIGN.md "Arithmetic spec"); only the
+// schedule differs, so the image is bit-identical to the other kernel variants and to the oracle.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "wave_common.h"
+
+namespace {
+
+constexpr uint32_t IDX_HIT = 0x80000000u;   // | record index (region * rc_cap + position)
+constexpr uint32_t IDX_BLACK = 0x7fffffffu; // the child hit a triangle: (0 * r1) / pdf
+constexpr int NQ_CAP = 128;                 // leaf-hit ring: <= 63 left over + 64 pushed
+constexpr int NQ_F = 7;                     // dwords per entry: d.xyz, b, D, ids, r1
+constexpr int NWIN = 4;                     // slot windows (rounds whose contributions may still be waiting for their hits' shading)
+constexpr int WIN_FLOATS = 2 * 3 * 64;      // [child 0|1][component][lane]
+constexpr int LEAF2_WAVE_FLOATS = NQ_CAP * NQ_F + NWIN * WIN_FLOATS;
+
+SKR_DEV uint32_t *lc_count(uint32_t *ctr, uint32_t region) { return ctr + SKR_PULL_STRIDE * region; }
+SKR_DEV uint32_t *lc_taken(uint32_t *ctr, uint32_t region) { return ctr + SKR_PULL_STRIDE * (SKR_P1_REGIONS + region); }
+SKR_DEV unsigned long long *lc_dead(uint32_t *ctr) { return reinterpret_cast<unsigned long long *>(ctr + SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS)); }
+SKR_DEV uint32_t *lc_prefix(uint32_t *ctr) { return ctr + SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS + 1u); } // 65 words: records before region r; [64] = all
+
+// the scene SoA staged into the workgroup's LDS (one __syncthreads); returns the kernel's view of it
+SKR_DEV SceneView stage_scene(const RenderParams &p, float4 *lds4, bool tris)
+{
+	const int ns = p.n_spheres, nl = p.n_lights;
+	float4 *s_geom = lds4, *s_amb = lds4 + ns + 1, *s_kd = s_amb + ns, *s_ks = s_kd + ns, *s_lights = s_ks + ns;
+	const int tid = threadIdx.x;
+	for(int i = tid; i < ns; i += 256)
+	{
+		s_geom[i] = p.sph_geom[i];
+		s_amb[i] = p.sph_amb[i];
+		s_kd[i] = p.sph_kd[i];
+		s_ks[i] = p.sph_ks[i];
+	}
+	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
+	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	__syncthreads();
+	return SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, tris ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
+}
+
+SKR_DEV void add_counters(const RenderParams &p, const Counters &cn, uint32_t shard, int lane)
+{
+	if(!p.counters) return;
+	const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays);
+	if(lane == 0)
+	{ // sharded: thousands of waves adding to one word serialise
+		unsigned long long *c4 = p.counters + 4u * (shard & (SKR_COUNTER_SHARDS - 1u));
+		if(a) atomicAdd(&c4[0], (unsigned long long) a);
+		if(b) atomicAdd(&c4[1], (unsigned long long) b);
+		if(c) atomicAdd(&c4[2], (unsigned long long) c);
+	}
+}
+
+struct F3p { float x, y, z; } __attribute__((packed, aligned(4)));
+SKR_DEV void store3(float *g, f3 v) { *reinterpret_cast<F3p *>(g) = F3p{v.x, v.y, v.z}; }
+
+// raytrace.h:171-186 + :189-192 / :221-224 for one traced child whose closest sphere is s: true = the child is a sphere
+// hit to be shaded; otherwise `black` says whether a triangle took it (else it left the scene)
+SKR_DEV bool classify_child(const SceneView &sv, f3 co, f3 d, float two_a, float four_a, const BestState &s, bool &black)
+{
+	black = false;
+	if(sv.nt > 0)
+	{ // the triangle walk needs the sphere's exact t to compare against
+		const float tmin = (s.best >= 0) ? near_root_exact(two_a, s.b, s.D) : __builtin_inff();
+		black = any_triangle_closer(sv, RayConst{co, d, two_a, four_a}, tmin);
+	}
+	return !black && s.best >= 0;
+}
+
+} // namespace
+
+// =====================================================================================================================
+// trace: one lane per sibling pair of a node
+// =====================================================================================================================
+template <bool TRIS>
+__global__ __launch_bounds__(256) void skr_trace_kernel(const RenderParams p)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
+	const uint32_t N = (uint32_t) p.num_path_traces, PP = (N + 1u) >> 1; // children, sibling pairs per node
+	const uint64_t n_pairs = (uint64_t) *p.nd_count * PP;
+	if((uint64_t) blockIdx.x * 256u >= n_pairs) return; // (uniform per workgroup)
+	const SceneView sv = stage_scene(p, lds4, TRIS);
+	const int tid = threadIdx.x, lane = tid & 63;
+	const uint32_t chunk = (uint32_t) blockIdx.x * 4u + (uint32_t) (tid >> 6);
+	const uint64_t tp = (uint64_t) chunk * 64u + (uint32_t) lane;
+	const bool valid = tp < n_pairs;
+	const uint32_t node = valid ? (uint32_t) (tp / PP) : 0u, j = valid ? (uint32_t) (tp - (uint64_t) node * PP) : 0u;
+	const bool second = valid && 2u * j + 1u < N;
+	Counters cn{0, 0, 0};
+	bool hit0 = false, hit1 = false;
+	float4 r0a = make_float4(0, 0, 0, 0), r0b = r0a, r1a = r0a, r1b = r0a;
+	uint32_t w0 = IDX_BLACK, w1 = IDX_BLACK;
+	if(valid)
+	{
+		const float4 *row = p.nd_src + (size_t) node * p.nd_src_stride;
+		const float4 a0 = row[0], a1 = row[1], a2 = row[2];
+		const f3 co = mk3(a0.x, a0.y, a0.z), Nn = mk3(a0.w, a1.x, a1.y);
+		const uint32_t pixel = __float_as_uint(a2.y), node_id = p.nd_src_level0 ? 0u : __float_as_uint(a2.z);
+		f3 nt, nb;
+		tangent_basis(Nn, nt, nb);
+		uint32_t rnd[4];
+		philox4x32_10(pixel, p.aa_index, node_id, j, p.seed_lo, p.seed_hi, rnd);
+		const float q1a = u31_to_unit(rnd[0]), q2a = u31_to_unit(rnd[1]), q1b = u31_to_unit(rnd[2]), q2b = u31_to_unit(rnd[3]);
+		const f3 d0 = gi_direction(q1a, q2a, Nn, nt, nb), d1 = gi_direction(q1b, q2b, Nn, nt, nb);
+		cn.rays += second ? 2u : 1u;
+		const RayPair rp = make_pair(d0, d1);
+		BestState s0, s1;
+		closest_pair_deferred(sv, co, d0, d1, second, rp, s0, s1);
+		bool black;
+		hit0 = classify_child(sv, co, d0, rp.two_a.x, rp.four_a.x, s0, black);
+		w0 = black ? IDX_BLACK : __float_as_uint(q1a);
+		r0a = make_float4(d0.x, d0.y, d0.z, s0.b);
+		r0b = make_float4(s0.D, q1a, __uint_as_float(node), __uint_as_float((uint32_t) (s0.best & 0xffff) | ((2u * j) << 16)));
+		if(second)
+		{
+			hit1 = classify_child(sv, co, d1, rp.two_a.y, rp.four_a.y, s1, black);
+			w1 = black ? IDX_BLACK : __float_as_uint(q1b);
+			r1a = make_float4(d1.x, d1.y, d1.z, s1.b);
+			r1b = make_float4(s1.D, q1b, __uint_as_float(node), __uint_as_float((uint32_t) (s1.best & 0xffff) | ((2u * j + 1u) << 16)));
+		}
+	}
+	// append the wave's hits to its region: rank by ballot, one atomic per wave
+	const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+	const uint32_t region = chunk & (SKR_P1_REGIONS - 1u);
+	const uint32_t n0h = (uint32_t) __popcll(m0), n1h = (uint32_t) __popcll(m1);
+	uint32_t base = 0;
+	if(n0h + n1h != 0u)
+	{
+		if(lane == 0) base = atomicAdd(lc_count(p.rc_ctr, region), n0h + n1h);
+		base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+	}
+	if(hit0)
+	{
+		const uint32_t pos = base + (uint32_t) lanes_below(m0), rec = region * p.rc_cap + pos;
+		float4 *dst = p.rc + (size_t) rec * 2;
+		dst[0] = r0a;
+		dst[1] = r0b;
+		w0 = IDX_HIT | rec;
+	}
+	if(hit1)
+	{
+		const uint32_t pos = base + n0h + (uint32_t) lanes_below(m1), rec = region * p.rc_cap + pos;
+		float4 *dst = p.rc + (size_t) rec * 2;
+		dst[0] = r1a;
+		dst[1] = r1b;
+		w1 = IDX_HIT | rec;
+	}
+	if(valid) *reinterpret_cast<uint2 *>(p.ix + (size_t) node * p.ix_stride + 2u * j) = make_uint2(w0, w1);
+	add_counters(p, cn, chunk, lane);
+}
+
+// One wave: prefix sums of a level's 64 region counts (dense node numbering of the activated records).
+__global__ __launch_bounds__(64) void skr_prefix_kernel(const RenderParams p)
+{
+	const int lane = threadIdx.x;
+	uint32_t v = *lc_count(p.rc_ctr, (uint32_t) lane);
+	uint32_t incl = v;
+#pragma unroll
+	for(int off = 1; off < 64; off <<= 1)
+	{
+		const uint32_t o = (uint32_t) __shfl_up((int) incl, off, 64);
+		if(lane >= off) incl += o;
+	}
+	uint32_t *pre = lc_prefix(p.rc_ctr);
+	pre[lane] = incl - v;
+	if(lane == 63) pre[64] = incl;
+}
+
+// =====================================================================================================================
+// activate (depth >= 4): record -> node of the next level
+// =====================================================================================================================
+// the hit a record describes, shaded: raytrace.h:194-207 (+ the child origin of :128)
+struct Activated {
+	f3 co, N, direct;
+	uint32_t pixel, node_id, sph, child;
+	float r1;
+};
+
+SKR_DEV Activated activate_record(const SceneView &sv, const RenderParams &p, bool act, uint32_t rec, Counters &cn)
+{
+	Activated a;
+	a.co = a.N = mk3(0, 0, 1);
+	a.direct = mk3(0, 0, 0);
+	a.pixel = a.node_id = a.sph = a.child = 0;
+	a.r1 = 0.0f;
+	if(act)
+	{
+		typedef float v4f __attribute__((ext_vector_type(4)));
+		const v4f *rv = reinterpret_cast<const v4f *>(p.rc + (size_t) rec * 2);
+		const v4f n0 = __builtin_nontemporal_load(&rv[0]), n1 = __builtin_nontemporal_load(&rv[1]); // streamed once
+		const f3 d = mk3(n0.x, n0.y, n0.z);
+		const float b = n0.w, D = n1.x;
+		a.r1 = n1.y;
+		const uint32_t parent = __float_as_uint(n1.z), sc = __float_as_uint(n1.w);
+		a.sph = sc & 0xffffu;
+		a.child = sc >> 16;
+		const float4 *row = p.nd_src + (size_t) parent * p.nd_src_stride;
+		const float4 p0 = row[0], p2 = row[2];
+		const f3 co0 = mk3(p0.x, p0.y, p0.z);
+		a.pixel = __float_as_uint(p2.y);
+		const uint32_t pnode = p.nd_src_level0 ? 0u : __float_as_uint(p2.z);
+		a.node_id = pnode * (uint32_t) p.num_path_traces + a.child + 1u; // DESIGN.md "RNG": child c of node n
+		const float two_a = 2 * dot3(d, d);
+		const float t = near_root_exact(two_a, b, D);
+		const f3 P = co0 + d * t;
+		a.N = normalize3(P - ld3(sv.geom[a.sph]));
+		cn.hits++;
+		a.direct = direct_light(sv, p, (int) a.sph, P, a.N, cn);
+		a.co = add_scalar(P, 0.00001f);
+	}
+	return a;
+}
+
+template <bool TRIS>
+__global__ __launch_bounds__(256) void skr_activate_kernel(const RenderParams p)
+{ // a workgroup covers 256 consecutive positions of one region; positions past the region's count exit
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
+	const uint32_t per_region = (p.rc_cap + 255u) / 256u;
+	const uint32_t region = (uint32_t) blockIdx.x / per_region, pos0 = ((uint32_t) blockIdx.x % per_region) * 256u;
+	const uint32_t cnt = *lc_count(p.rc_ctr, region);
+	if(pos0 >= cnt) return;
+	const SceneView sv = stage_scene(p, lds4, TRIS);
+	const uint32_t pos = pos0 + threadIdx.x;
+	const bool act = pos < cnt;
+	const uint32_t rec = region * p.rc_cap + pos;
+	Counters cn{0, 0, 0};
+	const Activated a = activate_record(sv, p, act, rec, cn);
+	if(act)
+	{
+		float4 *row = p.nd_dst + (size_t) (lc_prefix(p.rc_ctr)[region] + pos) * 4;
+		row[0] = make_float4(a.co.x, a.co.y, a.co.z, a.N.x);
+		row[1] = make_float4(a.N.y, a.N.z, a.direct.x, a.direct.y);
+		row[2] = make_float4(a.direct.z, __uint_as_float(a.pixel), __uint_as_float(a.node_id), __uint_as_float(a.sph));
+		row[3] = make_float4(a.r1, __uint_as_float(rec), 0.0f, 0.0f);
+	}
+	add_counters(p, cn, blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// =====================================================================================================================
+// leaf: one lane per record (FIRST: per level-0 node), its N leaf rays traced two per round
+// =====================================================================================================================
+namespace {
+
+struct Ring {
+	float *base; // SoA by field, NQ_CAP entries
+	int head, count; // wave-uniform
+};
+
+SKR_DEV void ring_push(Ring &q, bool pred, f3 d, float b, float D, uint32_t ids, float r1)
+{
+	const unsigned long long m = __ballot(pred);
+	if(pred)
+	{
+		int e = q.head + q.count + lanes_below(m); // head < cap, count + rank < cap
+		e -= (e >= NQ_CAP) ? NQ_CAP : 0;
+		float *r = q.base + e;
+		r[0 * NQ_CAP] = d.x;
+		r[1 * NQ_CAP] = d.y;
+		r[2 * NQ_CAP] = d.z;
+		r[3 * NQ_CAP] = b;
+		r[4 * NQ_CAP] = D;
+		r[5 * NQ_CAP] = __uint_as_float(ids);
+		r[6 * NQ_CAP] = r1;
+	}
+	q.count = uni(q.count + (int) __popcll(m));
+}
+
+// Shade the m <= 64 oldest queued leaf hits, one per lane: raytrace.h:194-213 with indirect = (0,0,0)/N (the leaf's own
+// children are shade(depth 0)), then its parent's accumulation term (:130) into the slot window of its round.
+// `co` = the child-ray origin of the node THIS lane holds (the hits' parents are lanes of this wave).
+SKR_DEV void leaf_batch(const SceneView &sv, const RenderParams &p, Ring &q, float *slots, f3 co, int lane, int m, Counters &cn)
+{
+	wave_lds_fence();
+	const bool act = lane < m;
+	DIAG_WAVE(9, 1);
+	DIAG_WAVE(10, m);
+	int e = q.head + (act ? lane : 0);
+	e -= (e >= NQ_CAP) ? NQ_CAP : 0;
+	const float *r = q.base + e;
+	const f3 d = mk3(r[0 * NQ_CAP], r[1 * NQ_CAP], r[2 * NQ_CAP]);
+	const float b = r[3 * NQ_CAP], D = r[4 * NQ_CAP], r1 = r[6 * NQ_CAP];
+	const uint32_t ids = __float_as_uint(r[5 * NQ_CAP]);
+	const int kl = (int) ((ids >> 16) & 63u);
+	const f3 co_k = shfl3(co, act ? kl : 0);
+	if(act)
+	{
+		const int sph = (int) (ids & 0xffffu);
+		const float two_a = 2 * dot3(d, d);
+		const float t = near_root_exact(two_a, b, D);
+		const f3 P = co_k + d * t;
+		const f3 Nn = normalize3(P - ld3(sv.geom[sph]));
+		cn.hits++;
+		const f3 direct = direct_light(sv, p, sph, P, Nn, cn);
+		const f3 total = mk3(0, 0, 0) / (float) p.num_path_traces;
+		const f3 colour = (direct / (float) 3.14159265358979323846 + total * 2.0f) * ld3(sv.kd[sph]);
+		const f3 c = (colour * r1) / (float) (1 / 3.14159265358979323846);
+		float *s = slots + (int) ((ids >> 23) & (NWIN - 1)) * WIN_FLOATS + (int) ((ids >> 22) & 1u) * 192 + kl;
+		s[0] = c.x;
+		s[64] = c.y;
+		s[128] = c.z;
+	}
+	int nh = q.head + m;
+	nh -= (nh >= NQ_CAP) ? NQ_CAP : 0;
+	q.head = uni(nh);
+	q.count = uni(q.count - m);
+	wave_lds_fence();
+}
+
+} // namespace
+
+#if defined(SKR_DIAG) && SKR_DIAG
+extern "C" void skr_diag_read_nodes(unsigned long long *out, int reset)
+{ // this translation unit's copy of the 32 event counters (device_math.h), summed over their 64 shards
+	unsigned long long h[32 * 64];
+	(void) hipDeviceSynchronize();
+	(void) hipMemcpyFromSymbol(h, HIP_SYMBOL(skr_diag), sizeof(h));
+	for(int i = 0; i < 32; i++)
+	{
+		out[i] = 0;
+		for(int k = 0; k < 64; k++) out[i] += h[i * 64 + k];
+	}
+	if(reset)
+	{
+		memset(h, 0, sizeof(h));
+		(void) hipMemcpyToSymbol(HIP_SYMBOL(skr_diag), h, sizeof(h));
+	}
+}
+#endif
+#if defined(SKR_TIMELINE) && SKR_TIMELINE
+// per-wave timeline of the leaf kernel (tools/leaf_timeline.py): entry, first unit in hand, last unit done, exit on the
+// device-wide 100 MHz clock, units done, and the wave's shader-clock cycles between entry and exit (the clock it ran at)
+static __device__ unsigned long long skr_leaf2_times[6 * 4096];
+extern "C" void skr_leaf2_times_read(unsigned long long *out)
+{
+	(void) hipDeviceSynchronize();
+	(void) hipMemcpyFromSymbol(out, HIP_SYMBOL(skr_leaf2_times), sizeof(unsigned long long) * 6 * 4096);
+}
+#endif
+#ifndef SKR_LEAF2_PRIO
+#define SKR_LEAF2_PRIO 0 // A/B builds
+#endif
+#ifndef SKR_LEAF2_OCC
+#define SKR_LEAF2_OCC 4 // waves per SIMD the register allocation aims at (A/B builds)
+#endif
+template <bool TRIS, bool FIRST>
+__global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const RenderParams p)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
+	const SceneView sv = stage_scene(p, lds4, TRIS); // the only workgroup barrier
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const uint32_t g = (uint32_t) blockIdx.x * 4u + (uint32_t) wave;
+	float *wbase = reinterpret_cast<float *>(lds4 + 4 * p.n_spheres + 1 + 2 * p.n_lights) + wave * LEAF2_WAVE_FLOATS;
+	Ring q{wbase, 0, 0};
+	float *slots = wbase + NQ_CAP * NQ_F;
+	const int N = p.num_path_traces, PP = (N + 1) >> 1;
+	const float pdf = (float) (1 / 3.14159265358979323846);
+	uint32_t region = g & (SKR_P1_REGIONS - 1u);
+	unsigned long long dead = 0; // regions this wave has seen exhausted
+	// FIRST: the level-0 nodes form virtual regions — unit u of the node array belongs to region u mod 64
+	const uint32_t n_first = FIRST ? *p.nd_count : 0u;
+	const uint32_t units_first = (n_first + 63u) >> 6;
+	Counters cn{0, 0, 0};
+	STAMP_DECL; // (diagnostic builds: 0 pull, 1 activation, 2 trace, 3 leaf shading, 4 pushes + window sums, 5 unit end)
+#if defined(SKR_TIMELINE) && SKR_TIMELINE
+	const unsigned long long wt_start = wall_clock64(), wc_start = __builtin_readcyclecounter();
+	unsigned long long wt_first = 0, wt_last = 0;
+	uint32_t wt_units = 0;
+#endif
+	for(;;)
+	{
+		uint32_t first = 0, step = 1;
+		int m = 0;
+		bool got = false;
+		for(;;)
+		{ // pull the next unit (wave-uniform): this region's, or another region's once this one is exhausted
+			uint32_t k = 0;
+			if(lane == 0) k = atomicAdd(lc_taken(p.rc_ctr, region), 1u);
+			k = (uint32_t) __builtin_amdgcn_readfirstlane((int) k);
+			if(FIRST)
+			{
+				const uint32_t u = k * SKR_P1_REGIONS + region;
+				if(u < units_first)
+				{
+					first = u * 64u;
+					m = (int) (n_first - first < 64u ? n_first - first : 64u);
+					got = true;
+				}
+			}
+			else
+			{
+				const uint32_t cnt = *lc_count(p.rc_ctr, region);
+				const uint32_t units = (cnt + 63u) >> 6;
+				if(k < units)
+				{
+					if(p.unit_strided)
+					{ // records k, k + units, k + 2 units, ...: a unit mixes hits from all over the region (equal unit costs)
+						first = k;
+						step = units;
+						m = (int) ((cnt - 1u - k) / units + 1u);
+					}
+					else
+					{
+						first = k * 64u;
+						m = (int) (cnt - first < 64u ? cnt - first : 64u);
+					}
+					got = true;
+				}
+			}
+			if(got) break;
+			// This region is exhausted.  The exhausted regions are published in one 64-bit mask: the atomic OR that adds this
+			// region returns everybody else's findings, and the wave goes to the first region after its own that nobody has
+			// seen dry — or leaves when there is none.
+			unsigned long long seen = 0;
+			if(lane == 0) seen = atomicOr(lc_dead(p.rc_ctr), 1ull << region);
+			const uint32_t lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) seen), hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (seen >> 32));
+			dead |= ((unsigned long long) hi << 32 | lo) | (1ull << region);
+			const unsigned long long live = ~dead;
+			if(live == 0ull) break;
+			const unsigned long long after = region == 63u ? 0ull : (live >> (region + 1u)) << (region + 1u); // regions above this one
+			region = (uint32_t) __builtin_ctzll(after ? after : live);
+		}
+		if(!got) break;
+		STAMP(0);
+#if defined(SKR_TIMELINE) && SKR_TIMELINE
+		if(wt_units == 0) wt_first = wall_clock64();
+#endif
+
+		// ---- the unit's records become the nodes their lanes hold
+		const bool act = lane < m;
+		f3 co = mk3(0, 0, 1), Nn = mk3(0, 0, 1), direct1 = mk3(0, 0, 0);
+		uint32_t pixel = 0, node_id = 0, out_idx = 0; // out_idx: output pixel (FIRST) or this record's index
+		if(FIRST)
+		{
+			if(act)
+			{
+				const float4 *row = p.nd_src + (size_t) (first + (uint32_t) lane) * p.nd_src_stride;
+				const float4 a0 = row[0], a1 = row[1], a2 = row[2];
+				co = mk3(a0.x, a0.y, a0.z);
+				Nn = mk3(a0.w, a1.x, a1.y);
+				direct1 = mk3(a1.z, a1.w, a2.x);
+				pixel = __float_as_uint(a2.y);
+				out_idx = __float_as_uint(a2.z);
+			}
+		}
+		else
+		{
+			out_idx = region * p.rc_cap + first + (uint32_t) lane * step;
+			const Activated a = activate_record(sv, p, act, out_idx, cn);
+			co = a.co;
+			Nn = a.N;
+			direct1 = a.direct;
+			pixel = a.pixel;
+			node_id = a.node_id;
+		}
+		f3 nt, nb;
+		tangent_basis(Nn, nt, nb);
+		// what is only needed when the unit is finished does not stay in registers: a level-0 node's row is read again,
+		// a record's direct light waits in the record's own result slot
+		if(!FIRST && act) store3(p.res_out + (size_t) out_idx * 3, direct1);
+		STAMP(1);
+		// ---- rounds: children 2j, 2j+1 of every lane's node
+		f3 acc = mk3(0, 0, 0);
+		for(int j = 0; j < PP; j++)
+		{
+			// The SIMD's arbiter serves its (persistent) waves by priority, then AGE: left alone, the oldest wave of a SIMD
+			// runs at full speed and the youngest on what is left, so that the waves that get nothing more from the queues
+			// leave early while the starved ones crawl through their last unit (per-wave timeline: last units done between
+			// 64 % and 100 % of the kernel's span).  The priority therefore follows the work a wave still has in hand.
+#if SKR_LEAF2_PRIO
+			{
+				const int left = 4 * (PP - j) / PP; // 4 .. 1
+				if(left >= 4) __builtin_amdgcn_s_setprio(3);
+				else if(left == 3) __builtin_amdgcn_s_setprio(2);
+				else if(left == 2) __builtin_amdgcn_s_setprio(1);
+				else __builtin_amdgcn_s_setprio(0);
+			}
+#endif
+			const bool second = 2 * j + 1 < N; // (wave-uniform)
+			float *win = slots + (j & (NWIN - 1)) * WIN_FLOATS + lane;
+			if(j >= NWIN)
+			{ // the window is reused: add round j - NWIN (its hits were shaded at the end of the previous round)
+				wave_lds_fence();
+				acc = acc + mk3(win[0], win[64], win[128]);
+				acc = acc + mk3(win[192], win[256], win[320]); // (rounds before the last always have both children)
+				wave_lds_fence();
+			}
+			bool hit0 = false, hit1 = false;
+			f3 d0 = mk3(0, 0, 1), d1 = mk3(0, 0, 1);
+			float b0 = 0, D0 = 0, b1 = 0, D1 = 0, q1a = 0, q1b = 0;
+			int s0b = 0, s1b = 0;
+			if(act)
+			{
+				uint32_t rnd[4];
+				philox4x32_10(pixel, p.aa_index, node_id, (uint32_t) j, p.seed_lo, p.seed_hi, rnd);
+				q1a = u31_to_unit(rnd[0]);
+				q1b = u31_to_unit(rnd[2]);
+				const float q2a = u31_to_unit(rnd[1]), q2b = u31_to_unit(rnd[3]);
+				d0 = gi_direction(q1a, q2a, Nn, nt, nb);
+				d1 = gi_direction(q1b, q2b, Nn, nt, nb);
+				cn.rays += second ? 2u : 1u;
+				const RayPair rp = make_pair(d0, d1);
+				BestState s0, s1;
+				closest_pair_deferred(sv, co, d0, d1, second, rp, s0, s1);
+				bool black;
+				hit0 = classify_child(sv, co, d0, rp.two_a.x, rp.four_a.x, s0, black);
+				if(!hit0)
+				{ // raytrace.h:189-192 / :221-224, then :130: total += (r1 * colour) / pdf
+					const f3 c = ((black ? mk3(0, 0, 0) : p.background) * q1a) / pdf;
+					win[0] = c.x;
+					win[64] = c.y;
+					win[128] = c.z;
+				}
+				b0 = s0.b;
+				D0 = s0.D;
+				s0b = s0.best;
+				if(second)
+				{
+					hit1 = classify_child(sv, co, d1, rp.two_a.y, rp.four_a.y, s1, black);
+					if(!hit1)
+					{
+						const f3 c = ((black ? mk3(0, 0, 0) : p.background) * q1b) / pdf;
+						win[192] = c.x;
+						win[256] = c.y;
+						win[320] = c.z;
+					}
+					b1 = s1.b;
+					D1 = s1.D;
+					s1b = s1.best;
+				}
+			}
+			STAMP(2);
+			const bool last = j + 1 == PP;
+			const uint32_t idj = ((uint32_t) lane << 16) | ((uint32_t) j << 23);
+			// the even children's hits, then the odd ones: never more than 63 + 64 queued, so a batch is shaded in between
+			// when both would not fit (rare: a round adds ~40 hits; the odd children's data then crosses that call)
+			ring_push(q, hit0, d0, b0, D0, (uint32_t) (s0b & 0xffff) | idj, q1a);
+			if(q.count + (int) __popcll(__ballot(hit1)) > NQ_CAP)
+			{
+				STAMP(4);
+				leaf_batch(sv, p, q, slots, co, lane, 64, cn);
+				STAMP(3);
+			}
+			ring_push(q, hit1, d1, b1, D1, (uint32_t) (s1b & 0xffff) | idj | (1u << 22), q1b);
+			for(;;)
+			{
+				bool go = q.count >= 64;
+				if(!go && q.count > 0)
+				{ // after the round: everything, if it was the last one; otherwise the hits of the round whose window the NEXT round reuses
+					go = last;
+					if(!go && j + 1 >= NWIN)
+					{
+						wave_lds_fence();
+						const uint32_t head_ids = (uint32_t) uni((int) __float_as_uint(q.base[5 * NQ_CAP + q.head]));
+						go = (int) (head_ids >> 23) <= j + 1 - NWIN;
+					}
+				}
+				if(!go) break;
+				STAMP(4);
+				leaf_batch(sv, p, q, slots, co, lane, q.count < 64 ? q.count : 64, cn);
+				STAMP(3);
+			}
+			STAMP(4);
+		}
+		// ---- the rounds still in their windows, in order
+		wave_lds_fence();
+		for(int jr = (PP > NWIN ? PP - NWIN : 0); jr < PP; jr++)
+		{
+			const float *win = slots + (jr & (NWIN - 1)) * WIN_FLOATS + lane;
+			acc = acc + mk3(win[0], win[64], win[128]);
+			if(2 * jr + 1 < N) acc = acc + mk3(win[192], win[256], win[320]);
+		}
+		wave_lds_fence();
+		if(act)
+		{ // raytrace.h:133 + :213
+			f3 direct;
+			uint32_t sph;
+			float r1 = 0.0f;
+			if(FIRST)
+			{
+				const float4 *row = p.nd_src + (size_t) (first + (uint32_t) lane) * p.nd_src_stride;
+				const float4 a1 = row[1], a2 = row[2];
+				direct = mk3(a1.z, a1.w, a2.x);
+				sph = __float_as_uint(a2.w);
+			}
+			else
+			{
+				const float *d3 = p.res_out + (size_t) out_idx * 3;
+				direct = mk3(d3[0], d3[1], d3[2]);
+				const float4 r1row = p.rc[(size_t) out_idx * 2 + 1];
+				r1 = r1row.y;
+				sph = __float_as_uint(r1row.w) & 0xffffu;
+			}
+			const f3 total = acc / (float) N;
+			const f3 colour = (direct / (float) 3.14159265358979323846 + total * 2.0f) * ld3(sv.kd[sph]);
+			if(FIRST) emit_sample(p, out_idx, colour);
+			else store3(p.res_out + (size_t) out_idx * 3, (colour * r1) / pdf); // :130, into the parent's sum
+		}
+		STAMP(5);
+#if defined(SKR_TIMELINE) && SKR_TIMELINE
+		wt_units++;
+		wt_last = wall_clock64();
+#endif
+	}
+#if defined(SKR_TIMELINE) && SKR_TIMELINE
+	if(lane == 0 && g < 4096u)
+	{
+		skr_leaf2_times[6 * g] = wt_start;
+		skr_leaf2_times[6 * g + 1] = wt_first;
+		skr_leaf2_times[6 * g + 2] = wt_last;
+		skr_leaf2_times[6 * g + 3] = wall_clock64();
+		skr_leaf2_times[6 * g + 4] = wt_units;
+		skr_leaf2_times[6 * g + 5] = __builtin_readcyclecounter() - wc_start;
+	}
+#endif
+#if defined(SKR_STAMPS) && SKR_STAMPS
+	if(p.counters && lane == 0)
+		for(int k = 0; k < 8; k++) atomicAdd(&p.counters[4u * SKR_COUNTER_SHARDS + k], st_acc[k]);
+#endif
+	add_counters(p, cn, g, lane);
+}
+
+// =====================================================================================================================
+// finalize: one lane per node
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void skr_finalize_kernel2(const RenderParams p)
+{
+	const uint32_t n = *p.nd_count;
+	const uint32_t node = (uint32_t) blockIdx.x * 256u + threadIdx.x;
+	if((uint32_t) blockIdx.x * 256u >= n) return;
+	if(node >= n) return;
+	const int N = p.num_path_traces;
+	const float pdf = (float) (1 / 3.14159265358979323846);
+	const uint32_t *w = p.ix + (size_t) node * p.ix_stride; // ix_stride is a multiple of 4 words: the 16-byte loads stay inside the row
+	f3 total = mk3(0, 0, 0);
+	for(int c0 = 0; c0 < N; c0 += 8)
+	{ // 8 children per trip: their words in two 16-byte loads, every gather issued before the first add
+		const uint4 wa = *reinterpret_cast<const uint4 *>(w + c0);
+		uint4 wb = make_uint4(IDX_BLACK, IDX_BLACK, IDX_BLACK, IDX_BLACK);
+		if(c0 + 4 < (int) p.ix_stride) wb = *reinterpret_cast<const uint4 *>(w + c0 + 4);
+		const uint32_t ww[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+		f3 v[8];
+#pragma unroll
+		for(int k = 0; k < 8; k++)
+		{
+			v[k] = mk3(0, 0, 0);
+			if(c0 + k < N && (ww[k] & IDX_HIT))
+			{
+				const float *r = p.res_in + (size_t) (ww[k] & ~IDX_HIT) * 3;
+				v[k] = mk3(r[0], r[1], r[2]);
+			}
+		}
+#pragma unroll
+		for(int k = 0; k < 8; k++)
+		{
+			if(c0 + k < N)
+			{
+				f3 term = v[k];
+				if(!(ww[k] & IDX_HIT))
+				{ // raytrace.h:189-192 / :221-224, then :130: (r1 * colour) / pdf; a triangle's (0 * r1) / pdf is +0
+					term = (ww[k] == IDX_BLACK) ? mk3(0, 0, 0) : (p.background * __uint_as_float(ww[k])) / pdf;
+				}
+				total = total + term;
+			}
+		}
+	}
+	const float4 *row = p.nd_src + (size_t) node * p.nd_src_stride;
+	const float4 a1 = row[1], a2 = row[2];
+	const f3 direct = mk3(a1.z, a1.w, a2.x);
+	const uint32_t sph = __float_as_uint(a2.w);
+	total = total / (float) N;
+	const f3 colour = (direct / (float) 3.14159265358979323846 + total * 2.0f) * ld3(p.sph_kd[sph]); // raytrace.h:213
+	if(p.nd_src_level0) emit_sample(p, __float_as_uint(a2.z), colour);
+	else
+	{
+		const float4 a3 = row[3];
+		store3(p.res_out + (size_t) __float_as_uint(a3.y) * 3, (colour * a3.x) / pdf);
+	}
+}
+
+// =====================================================================================================================
+// host side: the plan of one band (table sizes for the worst case: every pixel a node, every child a hit), selection, launch
+// =====================================================================================================================
+hipError_t skr_launch_primary(const RenderParams &p, dim3 grid, size_t lds, hipStream_t stream); // render_wave.hip
+hipError_t skr_launch_resolve(const RenderParams &p, hipStream_t stream);
+
+constexpr int SKR_NODE_LEVELS_MAX = 32;
+struct NodePlan {
+	int levels = 0;          // node / record levels 0 .. max_depth - 2
+	uint32_t band_nblk = 0;  // 16x16 pixel blocks per band
+	uint32_t stride0 = 3;    // float4 per level-0 node
+	uint32_t ix_stride = 0;
+	uint64_t nodes_max[SKR_NODE_LEVELS_MAX] = {};
+	uint32_t cap[SKR_NODE_LEVELS_MAX] = {};
+	size_t off_nodes[SKR_NODE_LEVELS_MAX] = {}, off_recs[SKR_NODE_LEVELS_MAX] = {}, off_res[SKR_NODE_LEVELS_MAX] = {}, off_ix[SKR_NODE_LEVELS_MAX] = {};
+	size_t off_ctr = 0, ctr_bytes = 0, off_stash = 0, total = 0, banded = 0;
+};
+static uint32_t *lc_prefix_host(uint32_t *ctr) { return ctr + SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS + 1u) + 64; } // the level's record count (skr_prefix_kernel)
+static const uint32_t LEAF2_GRID = 256u * SKR_LEAF2_OCC;                   // every workgroup resident: 256 CUs x 4 workgroups of 4 waves
+static const size_t LVL_CTR_WORDS = (size_t) SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS + 2u); // counts, taken, mask, prefix
+
+static bool plan_for(const RenderParams &p, uint32_t nblk, NodePlan &pl)
+{
+	const uint64_t N = (uint64_t) p.num_path_traces, PP = (N + 1) >> 1;
+	pl.levels = p.max_depth - 1;
+	if(pl.levels < 1 || pl.levels > SKR_NODE_LEVELS_MAX) return false;
+	pl.band_nblk = nblk;
+	pl.stride0 = p.max_depth <= 3 ? 3u : 4u;
+	pl.ix_stride = (uint32_t) ((2 * PP + 3) & ~3ull);
+	pl.nodes_max[0] = (uint64_t) nblk * 256u;
+	pl.cap[0] = 0;
+	for(int L = 1; L < pl.levels; L++)
+	{ // a region receives at most 128 hits from each of its trace waves (64 sibling pairs)
+		const uint64_t chunks = (pl.nodes_max[L - 1] * PP + 63) / 64;
+		const uint64_t cap = (chunks + SKR_P1_REGIONS - 1) / SKR_P1_REGIONS * 128;
+		if(cap * SKR_P1_REGIONS >= (1ull << 31)) return false; // record indices carry a flag bit
+		pl.cap[L] = (uint32_t) cap;
+		pl.nodes_max[L] = cap * SKR_P1_REGIONS;
+	}
+	size_t off = 0;
+	auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t) 255; return o; };
+	pl.ctr_bytes = (SKR_PULL_STRIDE + LVL_CTR_WORDS * (size_t) pl.levels) * sizeof(uint32_t); // [0] = level-0 node count, then one block per level
+	pl.off_ctr = take(pl.ctr_bytes);
+	pl.off_stash = take(256);
+	for(int L = 0; L < pl.levels; L++)
+	{
+		const size_t n = (size_t) pl.nodes_max[L];
+		if(L == 0) pl.off_nodes[L] = take(n * pl.stride0 * 16);
+		else
+		{
+			pl.off_recs[L] = take(n * 32);
+			pl.off_res[L] = take(n * 12 + 16);
+			if(L < pl.levels - 1) pl.off_nodes[L] = take(n * 64);
+		}
+		if(L < pl.levels - 1) pl.off_ix[L] = take(n * pl.ix_stride * 4 + 32);
+	}
+	pl.total = off;
+	pl.banded = off - (pl.off_nodes[0]); // what grows with the band; counters and the leaf kernel's stash are fixed
+	return true;
+}
+
+static uint64_t nodes_budget()
+{
+	uint64_t budget = 4ull << 30;
+	if(const char *e = getenv("SKR_LEVELS_BUDGET_MB")) budget = (uint64_t) (atoi(e) > 0 ? atoi(e) : 1) << 20; // tests: force several bands
+	return budget;
+}
+
+// the largest band (in 16x16 pixel blocks) whose worst-case tables fit the budget; false: not even one block does
+static bool skr_nodes_plan(const RenderParams &p, NodePlan &pl)
+{
+	const uint32_t bx = (uint32_t) (p.width + 15) / 16, by = (p.out_rows + 15) / 16;
+	const uint64_t budget = nodes_budget();
+	uint32_t lo = 1, hi = bx * by;
+	if(!plan_for(p, lo, pl) || pl.banded > budget) return false;
+	if(plan_for(p, hi, pl) && pl.banded <= budget) return true;
+	while(hi - lo > 1)
+	{ // plan size grows with the block count
+		const uint32_t mid = lo + (hi - lo) / 2;
+		if(plan_for(p, mid, pl) && pl.banded <= budget) lo = mid;
+		else hi = mid;
+	}
+	if(lo > bx) lo = lo / bx * bx; // whole block rows where possible
+	return plan_for(p, lo, pl);
+}
+
+// The node pipeline covers --gillum trees of any depth >= 2 on sphere scenes (<= 256 children per node, < 65536 spheres).
+// SKR_PIPELINE=nodes forces it wherever it applies; other values of SKR_PIPELINE exclude it.
+bool skr_nodes_supported(const RenderParams &p)
+{
+	if(!(p.monte_carlo && p.n_spheres > 0 && p.n_spheres < 65536 && p.max_depth >= 2 && p.num_path_traces > 0 && p.num_path_traces <= 256)) return false;
+	NodePlan pl;
+	return skr_nodes_plan(p, pl);
+}
+
+bool skr_nodes_selected(const RenderParams &p)
+{
+	const char *e = getenv("SKR_PIPELINE");
+	const bool forced = e && !strcmp(e, "nodes");
+	if(e && !forced) return false;
+	if(!skr_nodes_supported(p)) return false;
+	if(forced) return true;
+	// triangle meshes at depth 2..3 stay on the parent-queue pipeline (their rounds are long and few: DESIGN.md 5.0);
+	// beyond depth 3 this is the only pipeline
+	return p.n_tris <= 64 || p.max_depth > 3;
+}
+
+size_t skr_nodes_scratch_bytes(const RenderParams &p)
+{
+	NodePlan pl;
+	return skr_nodes_plan(p, pl) ? pl.total : 0;
+}
+
+size_t skr_nodes_lds_bytes(const RenderParams &p) { return ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 32 + (size_t) 4 * LEAF2_WAVE_FLOATS * sizeof(float); }
+
+template <bool FIRST>
+static hipError_t launch_leaf2(const RenderParams &p, size_t lds, hipStream_t stream)
+{
+	const void *fn = p.n_tris > 0 ? reinterpret_cast<const void *>(skr_leaf_kernel2<true, FIRST>) : reinterpret_cast<const void *>(skr_leaf_kernel2<false, FIRST>);
+	hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+	if(e != hipSuccess) return e;
+	if(p.n_tris > 0) hipLaunchKernelGGL((skr_leaf_kernel2<true, FIRST>), dim3(LEAF2_GRID), dim3(256), lds, stream, p);
+	else hipLaunchKernelGGL((skr_leaf_kernel2<false, FIRST>), dim3(LEAF2_GRID), dim3(256), lds, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const SkrTimingHook *hook)
+{
+	RenderParams p = p_in;
+	NodePlan pl;
+	if(!p.node_scratch || !skr_nodes_plan(p, pl)) return hipErrorInvalidValue;
+	char *base = reinterpret_cast<char *>(p.node_scratch);
+	uint32_t *ctr0 = reinterpret_cast<uint32_t *>(base + pl.off_ctr);
+	auto lvl_ctr = [&](int L) { return ctr0 + SKR_PULL_STRIDE + LVL_CTR_WORDS * (size_t) L; };
+	auto nodes = [&](int L) { return reinterpret_cast<float4 *>(base + pl.off_nodes[L]); };
+	const int nsamp = p.grid_size > 0 ? p.grid_size * p.grid_size : 1;
+	const size_t lds_scene = ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 32;
+	const size_t lds_leaf = skr_nodes_lds_bytes(p);
+	const bool tris = p.n_tris > 0;
+	const int D = p.max_depth, last = D - 2; // record levels 1 .. last; the leaf kernel works on level `last`
+	const uint32_t blocks_x = (uint32_t) (p.width + 15) / 16, blocks = blocks_x * ((p.out_rows + 15) / 16);
+	p.node_layout = 1;
+	p.blocks_x = blocks_x;
+	p.ix_stride = pl.ix_stride;
+	p.stash = reinterpret_cast<float *>(base + pl.off_stash);
+	p.qctr = ctr0; // [0]: the primary kernel counts its level-0 nodes here
+	{
+		const char *e = getenv("SKR_UNIT_STRIDE");
+		p.unit_strided = e ? (atoi(e) != 0) : 0u;
+	}
+	hipError_t e = hipSuccess;
+	for(int s = 0; s < nsamp; s++)
+	{
+		p.aa_index = (uint32_t) s;
+		for(uint32_t blk0 = 0; blk0 < blocks; blk0 += pl.band_nblk)
+		{ // every band is a complete pass: its level-0 nodes, their trees, their pixels
+			const bool timed = hook && s == nsamp - 1 && blk0 + pl.band_nblk >= blocks;
+			p.band_blk0 = blk0;
+			p.band_nblk = blocks - blk0 < pl.band_nblk ? blocks - blk0 : pl.band_nblk;
+			e = hipMemsetAsync(ctr0, 0, pl.ctr_bytes, stream);
+			if(e != hipSuccess) return e;
+			p.nd_dst = nodes(0);
+			p.nd_dst_stride = pl.stride0;
+			e = skr_launch_primary(p, dim3(p.band_nblk), lds_scene, stream);
+			if(e != hipSuccess) return e;
+			if(D == 2)
+			{ // the level-0 nodes' children are the leaves
+				p.nd_src = nodes(0);
+				p.nd_src_stride = pl.stride0;
+				p.nd_src_level0 = 1;
+				p.nd_count = ctr0;
+				p.rc_ctr = lvl_ctr(0);
+				if(timed && hook->start) (void) hipEventRecord(hook->start, stream);
+				e = launch_leaf2<true>(p, lds_leaf, stream);
+				if(timed && hook->stop) (void) hipEventRecord(hook->stop, stream);
+				if(e != hipSuccess) return e;
+				continue;
+			}
+			for(int L = 1; L <= last; L++)
+			{ // the children of level L - 1: hit records of level L, index words of level L - 1
+				p.nd_src = nodes(L - 1);
+				p.nd_src_stride = L == 1 ? pl.stride0 : 4u;
+				p.nd_src_level0 = L == 1;
+				p.nd_count = L == 1 ? ctr0 : lc_prefix_host(lvl_ctr(L - 1));
+				p.rc = reinterpret_cast<float4 *>(base + pl.off_recs[L]);
+				p.rc_cap = pl.cap[L];
+				p.rc_ctr = lvl_ctr(L);
+				p.ix = reinterpret_cast<uint32_t *>(base + pl.off_ix[L - 1]);
+				const unsigned grid_t = (unsigned) ((pl.nodes_max[L - 1] * (uint64_t) ((p.num_path_traces + 1) >> 1) + 255) / 256);
+				if(tris) hipLaunchKernelGGL(skr_trace_kernel<true>, dim3(grid_t), dim3(256), lds_scene, stream, p);
+				else hipLaunchKernelGGL(skr_trace_kernel<false>, dim3(grid_t), dim3(256), lds_scene, stream, p);
+				if(L < last)
+				{ // its records become the nodes of level L
+					hipLaunchKernelGGL(skr_prefix_kernel, dim3(1), dim3(64), 0, stream, p);
+					p.nd_dst = nodes(L);
+					p.nd_dst_stride = 4;
+					const unsigned grid_a = SKR_P1_REGIONS * ((pl.cap[L] + 255u) / 256u);
+					if(tris) hipLaunchKernelGGL(skr_activate_kernel<true>, dim3(grid_a), dim3(256), lds_scene, stream, p);
+					else hipLaunchKernelGGL(skr_activate_kernel<false>, dim3(grid_a), dim3(256), lds_scene, stream, p);
+				}
+			}
+			// leaf kernel: the records of the last level (their parents: level last - 1), results into res[last]
+			p.res_out = reinterpret_cast<float *>(base + pl.off_res[last]);
+			if(timed && hook->start) (void) hipEventRecord(hook->start, stream);
+			e = launch_leaf2<false>(p, lds_leaf, stream);
+			if(timed && hook->stop) (void) hipEventRecord(hook->stop, stream);
+			if(e != hipSuccess) return e;
+			for(int L = last - 1; L >= 0; L--)
+			{ // sums, deepest level first
+				p.nd_src = nodes(L);
+				p.nd_src_stride = L == 0 ? pl.stride0 : 4u;
+				p.nd_src_level0 = L == 0;
+				p.nd_count = L == 0 ? ctr0 : lc_prefix_host(lvl_ctr(L));
+				p.ix = reinterpret_cast<uint32_t *>(base + pl.off_ix[L]);
+				p.res_in = reinterpret_cast<const float *>(base + pl.off_res[L + 1]);
+				p.res_out = L == 0 ? nullptr : reinterpret_cast<float *>(base + pl.off_res[L]);
+				hipLaunchKernelGGL(skr_finalize_kernel2, dim3((unsigned) ((pl.nodes_max[L] + 255) / 256)), dim3(256), 0, stream, p);
+			}
+			e = hipGetLastError();
+			if(e != hipSuccess) return e;
+		}
+	}
+	if(p.grid_size > 0) return skr_launch_resolve(p, stream);
+	return hipSuccess;
+}

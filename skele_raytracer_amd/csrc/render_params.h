@@ -54,6 +54,27 @@ struct RenderParams {
 	float *slot0_scratch; // per-wave level-1 contribution slots of the GI kernel (behind the parent records)
 	float *acc;         // float3 per output pixel: the running `image[y][x] += shade(...)` of main.cpp:162 (AA only)
 	uint32_t aa_index;  // which AA sample this launch traces
+	// node pipeline (render_nodes.hip): the --gillum tree cut at every level.  A node is a shaded sphere hit; level 0 = the
+	// primary hits.  Node row layout (float4): [co.xyz N.x] [N.yz direct.xy] [direct.z pixel (out_pix | node id) sphere]
+	// [r1 record -- --] (the fourth row only at nd_stride 4: levels >= 1).
+	uint32_t node_layout;     // skr_primary_kernel writes its hits as level-0 nodes (nd_dst, nd_dst_stride) instead of 64-byte parent records
+	const float4 *nd_src;     // nodes whose children are traced / summed
+	float4 *nd_dst;           // nodes being written (primary hits; activated records)
+	uint32_t nd_src_stride, nd_dst_stride; // float4 per node: 3 or 4
+	uint32_t nd_src_level0;   // nd_src holds the primary hits: node id 0, row 2.z = output pixel index
+	const uint32_t *nd_count; // number of nodes in nd_src
+	float4 *rc;               // hit records of the level being produced (trace) or consumed (activate, leaf): [d.xyz b] [D r1 parent sphere|child<<16]
+	uint32_t rc_cap;          // records per region (SKR_P1_REGIONS regions)
+	uint32_t *rc_ctr;         // that level's counters: [STRIDE r] records in region r, [STRIDE (64 + r)] units handed out, [STRIDE 128] exhausted mask, [STRIDE 129 ..] prefix sums
+	uint32_t *ix;             // one word per child of the nd_src nodes, [node][ix_stride]: r1 (miss), IDX_BLACK (triangle), IDX_HIT | record
+	uint32_t ix_stride;       // words per node: 2 ceil(N/2) rounded up to a multiple of 4
+	uint32_t band_blk0, band_nblk, blocks_x; // node_layout: skr_primary_kernel covers the 16x16 pixel blocks [band_blk0, band_blk0 + band_nblk) of the launch (row-major, blocks_x per row)
+	void *node_scratch;       // (host) the pipeline's one allocation
+	const float *res_in;      // (colour r1)/pdf of every child record (finalize)
+	float *res_out;           // the same for this level's records (leaf kernel; finalize of a level >= 1)
+	float *stash;             // per-wave scratch of the leaf kernel (64 lanes x 8 floats per resident wave)
+	uint32_t unit_strided;    // leaf units take every U-th record of their region instead of 64 consecutive ones
+	uint32_t trace_chunks_max; // (host) bound on the trace kernel's 64-pair chunks: sizes rc_cap
 };
 
 // Optional timing of the dominant kernel of a launch (skr_renderer_kernel_ms): the launcher records the

@@ -27,7 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "shade_common.h"
+#include "wave_common.h"
 
 namespace {
 
@@ -63,39 +63,12 @@ struct Cfg {
 };
 constexpr int GILLUM_MAX = 256; // child index is 8 bits in HitRec.ids; Cfg<2>::S0_MAX
 
-// Diagnostic build only (-DSKR_STAMPS=1): per-phase cycle shares, summed over waves into
-// counters[4*SKR_COUNTER_SHARDS + phase].  Compiles to nothing otherwise.
-#if defined(SKR_STAMPS) && SKR_STAMPS
-#define STAMP_DECL unsigned long long st_t0 = __builtin_readcyclecounter(); unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define STAMP_ARG , unsigned long long &st_t0, unsigned long long (&st_acc)[8]
-#define STAMP_PASS , st_t0, st_acc
-#define STAMP(phase) do { const unsigned long long st_now = __builtin_readcyclecounter(); st_acc[phase] += st_now - st_t0; st_t0 = st_now; } while(0)
-#else
-#define STAMP_DECL
-#define STAMP_ARG
-#define STAMP_PASS
-#define STAMP(phase)
-#endif
-
-SKR_DEV void wave_lds_fence()
-{ // producer and consumer lanes are in the same wave: ordering only, no instruction
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-}
-
 // Slot offsets with this bit address the wave's HBM scratch instead of its LDS area.  The scratch is
 // written and read by lanes of ONE wave only: workgroup-scope accesses (plain global loads/stores; the
 // CU's L1 is coherent for its own waves) ordered by the wave's own vmcnt(0).  Plain stores stay in the
 // XCD's write-back L2, and a wave reuses its few KB for every group, so almost none of it reaches HBM
 // (sc1 write-through stores measured 0.85 GB per frame here).
 constexpr int SLOT_GLOBAL = 0x40000000;
-
-SKR_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-SKR_DEV f3 shfl3(f3 v, int src) { return mk3(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64)); }
-SKR_DEV int lanes_below(unsigned long long m)
-{
-	return (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
-}
 
 SKR_DEV void g_store(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 SKR_DEV float g_load(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -338,76 +311,6 @@ SKR_DEV void child_round(const Wave &w, const ParSrc &par, int kbase, int np, in
 	q_push(q, hit, h);
 }
 
-// ---- two sibling rays per lane ------------------------------------------------
-// Children 2j and 2j+1 of a node share their origin (raytrace.h:128), one Philox call
-// (DESIGN.md "RNG") and, per sphere, e = o - C and c = e.e - r^2; the per-ray part runs in
-// packed binary32 (device_math.h RayPair).  Same values as child_round(), half the issue slots.
-struct BestState {
-	int best;
-	float lo, hi, others_lo, b, D;
-};
-
-SKR_DEV void best_update(BestState &s, bool acc, int i, float lo, float hi, float b, float D)
-{
-	if(acc)
-	{
-		if(hi < s.hi)
-		{
-			s.others_lo = __builtin_fminf(s.others_lo, s.lo);
-			s.lo = lo;
-			s.hi = hi;
-			s.best = i;
-			s.b = b;
-			s.D = D;
-		}
-		else s.others_lo = __builtin_fminf(s.others_lo, lo);
-	}
-}
-
-SKR_DEV void best_resolve(const SceneView &sv, f3 o, f3 d, float four_a, BestState &s)
-{
-	if(s.best >= 0 && !(s.others_lo > s.hi))
-	{ // brackets overlap: the exact loop names the winner; recompute its coefficients
-		float tmin;
-		const RayConst r = make_ray(o, d);
-		s.best = closest_sphere_exact(sv, r, tmin);
-		const f3 e = o - ld3(sv.geom[s.best]);
-		s.b = 2 * dot3(d, e);
-		const float c = dot3(e, e) - sv.geom[s.best].w;
-		s.D = s.b * s.b - four_a * c;
-	}
-}
-
-SKR_DEV void closest_pair_deferred(const SceneView &sv, f3 o, f3 d0, f3 d1, bool second, const RayPair &rp, BestState &s0, BestState &s1)
-{
-	s0 = BestState{-1, __builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f, 0.0f};
-	s1 = s0;
-	float4 g_next = sv.geom[0];
-	for(int i = 0; i < sv.ns; i++)
-	{
-		const float4 g = g_next;
-		g_next = sv.geom[i + 1];
-		const f3 e = o - ld3(g);
-		const float c = dot3(e, e) - g.w;
-		f2 b, D;
-		pair_bD(rp, e, c, b, D);
-		const bool cand0 = (D.x >= 0.0f) && (b.x < 0.0f);
-		const bool cand1 = second && (D.y >= 0.0f) && (b.y < 0.0f);
-		if(cand0 || cand1)
-		{
-			f2 lo, hi;
-			pair_bracket(rp, b, D, lo, hi);
-			float l0 = lo.x, h0 = hi.x, l1 = lo.y, h1 = hi.y;
-			const bool acc0 = cand0 && bracket_decide(rp.sane0, rp.two_a.x, b.x, D.x, l0, h0);
-			const bool acc1 = cand1 && bracket_decide(rp.sane1, rp.two_a.y, b.y, D.y, l1, h1);
-			best_update(s0, acc0, i, l0, h0, b.x, D.x);
-			best_update(s1, acc1, i, l1, h1, b.y, D.y);
-		}
-	}
-	best_resolve(sv, o, d0, rp.four_a.x, s0);
-	if(second) best_resolve(sv, o, d1, rp.four_a.y, s1);
-}
-
 struct PairOut {
 	HitRec h0, h1;
 	bool hit0, hit1;
@@ -488,6 +391,8 @@ SKR_DEV void shade_leaf_batch(const Wave &w, Queue &q, const ParSrc &par, int m,
 {
 	wave_lds_fence();
 	const bool act = w.lane < m;
+	DIAG_WAVE(9, 1);
+	DIAG_WAVE(10, m);
 	HitRec h = q_read(q, act ? w.lane : 0);
 	const int k = (int) ((h.ids >> 16) & 0xffu);
 	const f3 co = fetch_parent_origin(par, act ? k : 0);
@@ -524,6 +429,8 @@ SKR_DEV f3 sum_slots(const Wave &w, int sbase, int k)
 SKR_DEV void expand_level1_hits(const Wave &w, int m, const HitRec &h, f3 co0, uint32_t pixel, Queue &q2, Counters &cn STAMP_ARG)
 {
 	const bool act = w.lane < m;
+	DIAG_WAVE(11, 1);
+	DIAG_WAVE(12, m);
 	Parent par1;
 	par1.co = par1.N = mk3(0, 0, 1);
 	par1.pixel = pixel;
@@ -894,50 +801,6 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 
 namespace {
 
-SKR_DEV void primary_ray(const RenderParams &p, int x, uint32_t y, uint32_t pixel, uint32_t aa, f3 &dir)
-{ // main.cpp:140-182
-	float u, v;
-	if(p.grid_size > 0)
-	{
-		uint32_t rnd[4];
-		philox4x32_10(pixel, aa, 0u, 0xFFFFFFFFu, p.seed_lo, p.seed_hi, rnd);
-		const float r = u31_to_unit(rnd[0]);
-		u = ((2 * (((float) x + r) * p.inv_width) - 1) * p.angle) * p.aspect;
-		v = (1 - 2 * (((float) (int) y + r) * p.inv_height)) * p.angle;
-	}
-	else
-	{
-		u = (float) (((2 * (((double) x + 0.5) * (double) p.inv_width) - 1) * (double) p.angle) * (double) p.aspect);
-		v = (float) ((1 - 2 * (((double) (int) y + 0.5) * (double) p.inv_height)) * (double) p.angle);
-	}
-	dir = (p.cam_dir + p.cam_right * u) + p.cam_up * v;
-}
-
-SKR_DEV void emit_sample(const RenderParams &p, uint32_t out_pix, f3 c)
-{ // one sample of one pixel is final: store it (1 spp) or add it to the running sum (AA, sample order = launch order)
-	if(p.grid_size > 0)
-	{
-		float *a = p.acc + (size_t) out_pix * 3;
-		if(p.aa_index == 0) { a[0] = c.x; a[1] = c.y; a[2] = c.z; }
-		else { a[0] = a[0] + c.x; a[1] = a[1] + c.y; a[2] = a[2] + c.z; }
-	}
-	else
-	{
-		if(p.rgbf)
-		{
-			float *o = p.rgbf + (size_t) out_pix * 3;
-			o[0] = c.x; o[1] = c.y; o[2] = c.z;
-		}
-		if(p.rgb)
-		{
-			unsigned char *o = p.rgb + (size_t) out_pix * 3;
-			o[0] = (unsigned char) quantise(c.x);
-			o[1] = (unsigned char) quantise(c.y);
-			o[2] = (unsigned char) quantise(c.z);
-		}
-	}
-}
-
 } // namespace
 
 // One workgroup = a 16x16 pixel block, one lane per pixel.  TRIS = false: no triangles in the scene, the walk is compiled out.
@@ -964,17 +827,21 @@ __global__ __launch_bounds__(256) void skr_primary_kernel(const RenderParams p)
 
 	const int wave = tid >> 6, lane = tid & 63;
 	const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
-	const int x = blockIdx.x * 16 + lx;
-	const uint32_t brow = blockIdx.y * 16 + ly, orow = p.band_row0 + brow;
+	// node pipeline: a band is a run of 16x16 blocks in row-major order (1-D grid); otherwise a band of rows (2-D grid)
+	const uint32_t blk = p.node_layout ? p.band_blk0 + blockIdx.x : 0u;
+	const uint32_t bx = p.node_layout ? blk % p.blocks_x : blockIdx.x, by = p.node_layout ? blk / p.blocks_x : blockIdx.y;
+	const int x = (int) bx * 16 + lx;
+	const uint32_t brow = by * 16 + ly, orow = p.band_row0 + brow;
 	const uint32_t k = orow / p.tile_rows;
 	const uint32_t y = (p.first_tile + k * p.tile_stride) * p.tile_rows + (orow - k * p.tile_rows);
-	const bool valid = x < p.width && brow < p.band_rows && orow < p.out_rows && y < (uint32_t) p.height;
+	const bool valid = x < p.width && (p.node_layout || brow < p.band_rows) && orow < p.out_rows && y < (uint32_t) p.height;
 	const uint32_t pixel = y * (uint32_t) p.width + (uint32_t) x;
 	const uint32_t out_pix = orow * (uint32_t) p.width + (uint32_t) x;
 
 	Counters cn{0, 0, 0};
 	f3 colour = mk3(0, 0, 0), co = mk3(0, 0, 0), N = mk3(0, 0, 1), kd = mk3(0, 0, 0);
 	bool hit = false;
+	int sph_hit = 0;
 	if(valid)
 	{
 		f3 dir;
@@ -988,6 +855,7 @@ __global__ __launch_bounds__(256) void skr_primary_kernel(const RenderParams p)
 		else
 		{
 			hit = true;
+			sph_hit = sph;
 			cn.hits++;
 			const f3 P = p.cam_pos + dir * tmin;
 			N = normalize3(P - ld3(sv.geom[sph]));
@@ -1010,11 +878,21 @@ __global__ __launch_bounds__(256) void skr_primary_kernel(const RenderParams p)
 	{
 		uint32_t idx = s_cnt[4] + (uint32_t) lanes_below(M);
 		for(int wv = 0; wv < wave; wv++) idx += s_cnt[wv];
-		float4 *rec = p.parents + (size_t) idx * 4;
-		rec[0] = make_float4(co.x, co.y, co.z, N.x);
-		rec[1] = make_float4(N.y, N.z, colour.x, colour.y);
-		rec[2] = make_float4(colour.z, kd.x, kd.y, kd.z);
-		rec[3] = make_float4(__uint_as_float(pixel), __uint_as_float(out_pix), 0.0f, 0.0f);
+		if(p.node_layout)
+		{ // a level-0 node of the node pipeline (render_params.h)
+			float4 *row = p.nd_dst + (size_t) idx * p.nd_dst_stride;
+			row[0] = make_float4(co.x, co.y, co.z, N.x);
+			row[1] = make_float4(N.y, N.z, colour.x, colour.y);
+			row[2] = make_float4(colour.z, __uint_as_float(pixel), __uint_as_float(out_pix), __uint_as_float((uint32_t) sph_hit));
+		}
+		else
+		{
+			float4 *rec = p.parents + (size_t) idx * 4;
+			rec[0] = make_float4(co.x, co.y, co.z, N.x);
+			rec[1] = make_float4(N.y, N.z, colour.x, colour.y);
+			rec[2] = make_float4(colour.z, kd.x, kd.y, kd.z);
+			rec[3] = make_float4(__uint_as_float(pixel), __uint_as_float(out_pix), 0.0f, 0.0f);
+		}
 	}
 	else if(valid) emit_sample(p, out_pix, colour); // this sample of this pixel is final
 	if(p.counters)
@@ -1205,6 +1083,24 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 //   skr_finalize_kernel  one lane per parent: the N slots strictly in child order, (direct/pi + 2 indirect) * kd
 // Same values, same order of every float sum: the image is bit-identical to the other paths.
 // =====================================================================================
+#if defined(SKR_DIAG) && SKR_DIAG
+extern "C" void skr_diag_read(unsigned long long *out, int reset)
+{ // 32 counters, summed over their 64 shards
+	unsigned long long h[32 * 64];
+	(void) hipDeviceSynchronize();
+	(void) hipMemcpyFromSymbol(h, HIP_SYMBOL(skr_diag), sizeof(h));
+	for(int i = 0; i < 32; i++)
+	{
+		out[i] = 0;
+		for(int k = 0; k < 64; k++) out[i] += h[i * 64 + k];
+	}
+	if(reset)
+	{
+		memset(h, 0, sizeof(h));
+		(void) hipMemcpyToSymbol(HIP_SYMBOL(skr_diag), h, sizeof(h));
+	}
+}
+#endif
 #if defined(SKR_STAMPS) && SKR_STAMPS
 static __device__ unsigned long long skr_leaf_times[5 * 4096];
 extern "C" void skr_leaf_times_read(unsigned long long *out)
@@ -1808,4 +1704,18 @@ hipError_t skr_launch_queue(const RenderParams &p_in, hipStream_t stream, const 
 		return hipGetLastError();
 	}
 	return hipSuccess;
+}
+
+// ---- launch wrappers for the node pipeline (render_nodes.hip)
+hipError_t skr_launch_primary(const RenderParams &p, dim3 grid, size_t lds, hipStream_t stream)
+{
+	if(p.n_tris > 0) hipLaunchKernelGGL(skr_primary_kernel<true>, grid, dim3(256), lds, stream, p);
+	else hipLaunchKernelGGL(skr_primary_kernel<false>, grid, dim3(256), lds, stream, p);
+	return hipGetLastError();
+}
+hipError_t skr_launch_resolve(const RenderParams &p, hipStream_t stream)
+{
+	const size_t n = (size_t) p.width * p.out_rows;
+	hipLaunchKernelGGL(skr_resolve_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, p);
+	return hipGetLastError();
 }

@@ -204,13 +204,16 @@ SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second,
 {
 	const f3 o = add_scalar(P, 0.000001f);
 	const RayPair rp = make_pair(L0, L1);
+	const PairAny pa{rp.two_a, rp.two_a * 0.25f, rp.sane0, rp.sane1};
 	occ0 = false;
 	occ1 = !second;
 	float4 g_next = sv.geom[0];
+#pragma unroll 2 // (as in closest_pair_deferred)
 	for(int i = 0; i < sv.ns; i++)
 	{
 		const float4 g = g_next;
 		g_next = sv.geom[i + 1];
+		__builtin_amdgcn_sched_barrier(0); // (as in closest_pair_deferred)
 		const f3 e = o - ld3(g);
 		const float c = dot3(e, e) - g.w;
 		f2 b, D;
@@ -218,13 +221,22 @@ SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second,
 		// b >= 0 or D < 0 (or NaN): certain miss for that ray
 		const bool cand0 = !occ0 && (D.x >= 0.0f) && (b.x < 0.0f);
 		const bool cand1 = !occ1 && (D.y >= 0.0f) && (b.y < 0.0f);
+		DIAG_WAVE(4, 1);
 		if(cand0 || cand1)
 		{
-			f2 lo, hi;
-			pair_bracket(rp, b, D, lo, hi);
-			float l0 = lo.x, h0 = hi.x, l1 = lo.y, h1 = hi.y;
-			if(cand0) occ0 = bracket_decide(rp.sane0, rp.two_a.x, b.x, D.x, l0, h0);
-			if(cand1) occ1 = bracket_decide(rp.sane1, rp.two_a.y, b.y, D.y, l1, h1);
+			DIAG_WAVE(5, 1);
+			DIAG_LANES(6);
+			f2 m, al, rl;
+			pair_any_m(pa, b, m, al, rl);
+			if(cand0) occ0 = any_decide(pa.sane0, pa.two_a.x, pa.quarter.x, b.x, D.x, m.x, al.x, rl.x);
+			if(cand1) occ1 = any_decide(pa.sane1, pa.two_a.y, pa.quarter.y, b.y, D.y, m.y, al.y, rl.y);
+#if defined(SKR_DIAG) && SKR_DIAG
+			{
+				const unsigned long long c0 = __ballot(cand0), c1 = __ballot(cand1), o0 = __ballot(cand0 && occ0), o1 = __ballot(cand1 && occ1);
+				DIAG_WAVE(15, __popcll(c0) + __popcll(c1)); // candidate shadow rays
+				DIAG_WAVE(16, __popcll(o0) + __popcll(o1)); // occluded by this sphere
+			}
+#endif
 		}
 		if(__all(occ0 && occ1)) break;
 	}

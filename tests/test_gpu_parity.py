@@ -60,6 +60,11 @@ CASES = [
     ("spheres2_gi4_js2_d2", "spheres2.scn", 160, 90, dict(gillum=4, jsample=2, depth=2, shadow=True, seed=5)),
     ("spheres2_gi3_d4", "spheres2.scn", 96, 54, dict(gillum=3, depth=4, shadow=True, seed=12)),
     ("spheres2_gi2_d6", "spheres2.scn", 64, 36, dict(gillum=2, depth=6, shadow=True, seed=8)),
+    ("spheres2_gi2_d8", "spheres2.scn", 48, 27, dict(gillum=2, depth=8, shadow=True, seed=8)),        # beyond the old cap of 6 (main.cpp:318-329 takes any positive depth)
+    ("spheres2_gi3_d5_js2", "spheres2.scn", 40, 23, dict(gillum=3, depth=5, jsample=2, shadow=True, seed=4)),
+    ("spheres2_nogi_d9", "spheres2.scn", 64, 36, dict(depth=9, shadow=True)),                        # without --gillum shade() never recurses: the depth-1 image
+    ("dragon_gi4_d7", "dragon.scn", 64, 48, dict(gillum=4, depth=7)),                                 # no spheres: nothing to recurse under
+    ("test_mixed_gi3_d4", "test.scn", 64, 36, dict(gillum=3, depth=4, shadow=True, seed=3)),          # triangles under the node pipeline
     ("spheres2_gi5_odd", "spheres2.scn", 100, 57, dict(gillum=5, shadow=True, seed=77)),   # odd N: half-used Philox pair; ragged tiles
     ("spheres2_gi1", "spheres2.scn", 64, 36, dict(gillum=1, shadow=True, seed=1)),
     ("spheres2_gi0_nan", "spheres2.scn", 64, 36, dict(gillum=0, shadow=True)),           # N=0: 0/0 -> NaN -> 255 (main.cpp:205)
@@ -168,8 +173,10 @@ def test_unsupported_configs_fail_loudly(gpu):
     r = renderer("spheres2.scn")
     with pytest.raises(skr.SkrError):
         r.render(skr.Options(64, 36, depth=0))
-    with pytest.raises(skr.SkrError, match="depth"):
-        r.render(skr.Options(64, 36, gillum=2, depth=9))
+    with pytest.raises(skr.SkrError, match="2\\^32"):  # tree node ids are 32-bit RNG counter words
+        r.render(skr.Options(64, 36, gillum=16, depth=10))
+    with pytest.raises(skr.SkrError, match="budget"):   # one 16x16 block of --gillum 16 --depth 7 needs ~12 GB of tables
+        r.render(skr.Options(64, 36, gillum=16, depth=7))
 
 
 def test_cli_drop_in_writes_the_same_ppm(gpu, oracle, tmp_path):
@@ -254,16 +261,15 @@ def test_full_size_config5_rows_against_oracle(gpu, oracle):
 
 
 def test_all_kernel_variants_agree(gpu, monkeypatch):
-    """The product has one arithmetic spec and several schedules: the level-queue pipeline (default for --gillum at
-    depth 3 on sphere scenes; in one band or several), the parent-queue pipeline, the single wave-streaming megakernel
-    with each per-wave tile shape and each LDS/VGPR budget, and the per-pixel kernel.  Every one of them must produce
-    the same bits and the same ray counts."""
+    """The product has one arithmetic spec and several schedules: the node pipeline (default for --gillum on sphere scenes;
+    in one band or several), the level-queue pipeline of round 1, the parent-queue pipeline, the single wave-streaming
+    megakernel with each per-wave tile shape and each LDS/VGPR budget, and the per-pixel kernel.  Every one of them must
+    produce the same bits and the same ray counts."""
     w, h = 176, 99
-    opt = skr.Options(w, h, gillum=8, shadow=True, seed=31)
     r = renderer("spheres2.scn")
-    knobs = ("SKR_PIPELINE", "SKR_KERNEL", "SKR_OCC", "SKR_TILE", "SKR_LEVELS_BUDGET_MB")
+    knobs = ("SKR_PIPELINE", "SKR_KERNEL", "SKR_OCC", "SKR_TILE", "SKR_LEVELS_BUDGET_MB", "SKR_UNIT_STRIDE")
 
-    def run(env):
+    def run(opt, env):
         for k in knobs:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -273,29 +279,66 @@ def test_all_kernel_variants_agree(gpu, monkeypatch):
         gpu.cuda.synchronize()
         return rgb.cpu().numpy(), rgbf.cpu().numpy().view(np.uint32), r.counters(), r.kernel_variant()
 
-    base = run({})
-    assert base[3] == "level_queues_v4"
+    opt = skr.Options(w, h, gillum=8, shadow=True, seed=31)
+    base = run(opt, {})
+    assert base[3] == "node_levels_v5"
     seen = {base[3]}
-    for env in ({"SKR_LEVELS_BUDGET_MB": "1"},  # 1 MiB of level-1 records: 16-row bands, 7 of them
+    for env in ({"SKR_LEVELS_BUDGET_MB": "2"},  # 2 MiB of tables: bands of a few 16x16 blocks
+                {"SKR_UNIT_STRIDE": "1"},
+                {"SKR_PIPELINE": "levels"}, {"SKR_PIPELINE": "levels", "SKR_LEVELS_BUDGET_MB": "1"},
                 {"SKR_PIPELINE": "queue"}, {"SKR_PIPELINE": "queue", "SKR_OCC": "2"}, {"SKR_PIPELINE": "queue", "SKR_OCC": "3"},
                 {"SKR_PIPELINE": "mega"}, {"SKR_PIPELINE": "mega", "SKR_TILE": "64"}, {"SKR_PIPELINE": "mega", "SKR_TILE": "16"},
-                {"SKR_PIPELINE": "mega", "SKR_OCC": "2"}, {"SKR_KERNEL": "v1"}):
-        got = run(env)
+                {"SKR_PIPELINE": "mega", "SKR_OCC": "2"}, {"SKR_PIPELINE": "mega", "SKR_KERNEL": "v1"}):
+        got = run(opt, env)
         seen.add(got[3])
         assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
         assert got[2] == base[2], env
-    assert seen == {"level_queues_v4", "parent_queue_v3", "wave_streaming_v2", "lane_per_pixel_dfs_v1f"}
+    assert seen == {"node_levels_v5", "level_queues_v4", "parent_queue_v3", "wave_streaming_v2", "lane_per_pixel_dfs_v1f"}
+    # depth 2 (the leaf kernel works on the primary hits) and depth 4 (one activate + trace level in between)
+    for opt2, others in ((skr.Options(w, h, gillum=8, shadow=True, depth=2, seed=31), ({"SKR_PIPELINE": "queue"}, {"SKR_PIPELINE": "mega"})),
+                         (skr.Options(96, 54, gillum=3, shadow=True, depth=4, seed=31), ({"SKR_PIPELINE": "mega", "SKR_KERNEL": "v1"}, {"SKR_LEVELS_BUDGET_MB": "8"}))):
+        b2 = run(opt2, {})
+        assert b2[3] == "node_levels_v5"
+        for env in others:
+            got = run(opt2, env)
+            assert np.array_equal(got[0], b2[0]) and np.array_equal(got[1], b2[1]) and got[2] == b2[2], env
     for k in knobs:
         monkeypatch.delenv(k, raising=False)
 
 
+def test_node_pipeline_in_bands_on_triangles_and_deep(gpu, oracle, monkeypatch):
+    """The node pipeline against the oracle where it is not in one piece or not the default: bands of a few 16x16 blocks
+    with AA (several bands x several samples), odd N, a triangle scene it is forced onto, N = 255 and 256, depth 5 in bands."""
+    for scn, w, h, kw, env in (("test.scn", 96, 54, dict(gillum=4, shadow=True, seed=3), {"SKR_PIPELINE": "nodes"}),
+                               ("spheres2.scn", 200, 113, dict(gillum=6, jsample=2, shadow=True, seed=9), {"SKR_LEVELS_BUDGET_MB": "2"}),
+                               ("spheres2.scn", 131, 77, dict(gillum=5, shadow=True, seed=4), {"SKR_LEVELS_BUDGET_MB": "1"}),
+                               ("spheres2.scn", 131, 77, dict(gillum=3, depth=5, shadow=True, seed=4), {"SKR_LEVELS_BUDGET_MB": "24"}),
+                               ("bear.scn", 160, 90, dict(gillum=255, seed=4), {}),
+                               ("spheres2.scn", 24, 14, dict(gillum=256, depth=2, seed=2), {})):
+        for k in ("SKR_PIPELINE", "SKR_LEVELS_BUDGET_MB"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = renderer(scn)
+        r.counters(reset=True)
+        rgb, rgbf = r.render(skr.Options(w, h, **kw), want_float=True)
+        gpu.cuda.synchronize()
+        assert r.kernel_variant() == "node_levels_v5", (scn, kw, env)
+        o_rgb, o_f, st = oracle.render(scene_path(scn), w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, **kw)
+        compare(rgb.cpu().numpy(), rgbf.cpu().numpy(), o_rgb, o_f, "%s %s %s" % (scn, kw, env))
+        cnt = r.counters()
+        assert cnt["radiance_rays"] == int(st[0]) and cnt["sphere_hits"] == int(st[1]) and cnt["shadow_rays"] == int(st[2])
+    for k in ("SKR_PIPELINE", "SKR_LEVELS_BUDGET_MB"):
+        monkeypatch.delenv(k, raising=False)
+
+
 def test_level_queue_pipeline_in_bands_and_on_triangles(gpu, oracle, monkeypatch):
-    """The default --gillum path against the oracle where it is not the default or not in one piece: forced onto a
-    triangle scene (SKR_PIPELINE=levels), in 16-row bands with AA (several bands x several samples), and with an odd N."""
+    """Round 1's level-queue pipeline (SKR_PIPELINE=levels; kept for A/B runs) against the oracle: on a triangle scene,
+    in 16-row bands with AA (several bands x several samples), and with an odd N."""
     for scn, w, h, kw, env in (("test.scn", 96, 54, dict(gillum=4, shadow=True, seed=3), {"SKR_PIPELINE": "levels"}),
-                               ("spheres2.scn", 200, 113, dict(gillum=6, jsample=2, shadow=True, seed=9), {"SKR_LEVELS_BUDGET_MB": "1"}),
-                               ("spheres2.scn", 131, 77, dict(gillum=5, shadow=True, seed=4), {"SKR_LEVELS_BUDGET_MB": "2"}),
-                               ("bear.scn", 160, 90, dict(gillum=255, seed=4), {})):
+                               ("spheres2.scn", 200, 113, dict(gillum=6, jsample=2, shadow=True, seed=9), {"SKR_PIPELINE": "levels", "SKR_LEVELS_BUDGET_MB": "1"}),
+                               ("spheres2.scn", 131, 77, dict(gillum=5, shadow=True, seed=4), {"SKR_PIPELINE": "levels", "SKR_LEVELS_BUDGET_MB": "2"}),
+                               ("bear.scn", 160, 90, dict(gillum=255, seed=4), {"SKR_PIPELINE": "levels"})):
         for k in ("SKR_PIPELINE", "SKR_LEVELS_BUDGET_MB"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():

@@ -1,0 +1,173 @@
+// Dev aid (not product): per-instruction issue cost on gfx950 at 1 / 2 / 4 waves per SIMD, measured with s_memtime.
+// Each wave runs ITER x 16 independent instances of one instruction; prints shader cycles per wave-instruction
+// as seen by ONE wave (a) and per SIMD (a / waves-per-SIMD): the second is the throughput figure.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define ITER 2048
+#define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+
+template <int OP>
+__global__ __launch_bounds__(256) void k(unsigned long long *out, float seed)
+{
+	__shared__ float lds[1024];
+	lds[threadIdx.x] = seed + threadIdx.x;
+	__syncthreads();
+	float r[16];
+	double dd[16];
+	unsigned long long uu[16];
+#pragma unroll
+	for(int i = 0; i < 16; i++) { r[i] = seed + i + threadIdx.x; dd[i] = r[i]; uu[i] = (unsigned long long) (i + threadIdx.x); }
+	float2 p[16];
+#pragma unroll
+	for(int i = 0; i < 16; i++) p[i] = make_float2(r[i], r[i] + 1);
+	float4 q[4];
+	int addr = (threadIdx.x & 63) * 4, zero = 0;
+	const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+	for(int it = 0; it < ITER; it++)
+	{
+		if(OP == 0) {
+#define X(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r[i]) : "v"(seed));
+			REP16(X)
+#undef X
+		} else if(OP == 1) {
+#define X(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 15]));
+			REP16(X)
+#undef X
+		} else if(OP == 2) {
+#define X(i) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(dd[i]) : "v"(dd[(i + 1) & 15]));
+			REP16(X)
+#undef X
+		} else if(OP == 3) {
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(uu[i]) : "v"((unsigned) i), "v"((unsigned) threadIdx.x) : "vcc");
+			REP16(X)
+#undef X
+		} else if(OP == 4) {
+#define X(i) asm volatile("v_sqrt_f32 %0, %0" : "+v"(r[i]));
+			REP16(X)
+#undef X
+		} else if(OP == 5) {
+#define X(i) asm volatile("v_rcp_f32 %0, %0" : "+v"(r[i]));
+			REP16(X)
+#undef X
+		} else if(OP == 6) {
+#define X(i) asm volatile("v_mov_b32 %0, %1" : "=v"(r[i]) : "v"(seed));
+			REP16(X)
+#undef X
+		} else if(OP == 7) {
+#define X(i) asm volatile("ds_bpermute_b32 %0, %1, %0" : "+v"(r[i]) : "v"(addr));
+			REP16(X)
+#undef X
+			asm volatile("s_waitcnt lgkmcnt(0)");
+		} else if(OP == 8) {
+#define X(i) asm volatile("ds_read_b128 %0, %1" : "=v"(q[i & 3]) : "v"(zero));
+			REP16(X)
+#undef X
+			asm volatile("s_waitcnt lgkmcnt(0)");
+		} else if(OP == 9) {
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(r[i]) : "v"(seed));
+			REP16(X)
+#undef X
+		} else if(OP == 10) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(p[i]) : "v"(p[(i + 1) & 15]));
+			REP16(X)
+#undef X
+		} else if(OP == 11) {
+#define X(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(seed) : "vcc");
+			REP16(X)
+#undef X
+		} else if(OP == 12) {
+#define X(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(dd[i]) : "v"(dd[(i + 1) & 15]));
+			REP16(X)
+#undef X
+		} else if(OP == 13) {
+#define X(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(r[i]), "v"(seed) : "vcc");
+			REP16(X)
+#undef X
+		} else if(OP == 14) {
+#define X(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(r[i]) : "v"(seed));
+			REP16(X)
+#undef X
+		} else if(OP == 15) {
+#define X(i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r[i]) : "v"(seed));
+			REP16(X)
+#undef X
+		} else if(OP == 16) {
+#define X(i) asm volatile("v_rsq_f64 %0, %0" : "+v"(dd[i]));
+			REP16(X)
+#undef X
+		} else if(OP == 17) {
+#define X(i) asm volatile("v_readlane_b32 s20, %0, 3" : : "v"(r[i]) : "s20");
+			REP16(X)
+#undef X
+		} else if(OP == 18) {
+#define X(i) asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(r[i]));
+			REP16(X)
+#undef X
+			asm volatile("s_waitcnt lgkmcnt(0)");
+		}
+	}
+	const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+	float acc = 0;
+	double dacc = 0;
+#pragma unroll
+	for(int i = 0; i < 16; i++) { acc += r[i] + p[i].x + p[i].y + (float) uu[i]; dacc += dd[i]; }
+	acc += q[0].x + q[1].y + q[2].z + q[3].w;
+	if(acc == 123.456f || dacc == 1.25) out[0] = 1; // keep results alive
+	if((threadIdx.x & 63) == 0) out[1 + blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int OP>
+static void run(const char *name)
+{
+	for(int wps = 1; wps <= 4; wps *= 2)
+	{ // 256-thread blocks = one wave per SIMD each; wps blocks per CU
+		const int blocks = 256 * wps;
+		unsigned long long *d;
+		hipMalloc(&d, (1 + blocks * 4) * 8);
+		hipMemset(d, 0, (1 + blocks * 4) * 8);
+		hipEvent_t e0, e1;
+		hipEventCreate(&e0);
+		hipEventCreate(&e1);
+		hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1.0001f);
+		hipEventRecord(e0);
+		hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1.0001f);
+		hipEventRecord(e1);
+		hipDeviceSynchronize();
+		float ms = 0;
+		hipEventElapsedTime(&ms, e0, e1);
+		std::vector<unsigned long long> h(1 + blocks * 4);
+		hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+		double sum = 0;
+		for(int i = 0; i < blocks * 4; i++) sum += (double) h[1 + i];
+		const double cyc = sum / (blocks * 4) / (ITER * 16.0);
+		// s_memtime ticks at a constant 100 MHz on this part? report both: ticks per instr, and wall ns per instr per SIMD
+		printf("%-16s waves/SIMD %d: memtime ticks per wave-instr %.3f ; wall ns per wave-instr per SIMD %.3f (= %.2f cyc @2.4GHz)\n", name, wps, cyc,
+			   ms * 1e6 / (ITER * 16.0) / wps, ms * 1e6 / (ITER * 16.0) / wps * 2.4);
+		hipFree(d);
+	}
+}
+
+int main()
+{
+	run<0>("v_mul_f32");
+	run<9>("v_fma_f32");
+	run<1>("v_pk_mul_f32");
+	run<10>("v_pk_fma_f32");
+	run<2>("v_fma_f64");
+	run<12>("v_mul_f64");
+	run<16>("v_rsq_f64");
+	run<3>("v_mad_u64_u32");
+	run<14>("v_mul_lo_u32");
+	run<15>("v_xor_b32");
+	run<4>("v_sqrt_f32");
+	run<5>("v_rcp_f32");
+	run<6>("v_mov_b32");
+	run<11>("v_cndmask_b32");
+	run<13>("v_cmp_lt_f32");
+	run<17>("v_readlane_b32");
+	run<7>("ds_bpermute_b32");
+	run<8>("ds_read_b128 bc");
+	run<18>("ds_write_b32");
+	return 0;
+}
