@@ -3,12 +3,14 @@
 
 Metric (BASELINE.json): Mrays/sec + frame ms, scenes/spheres2.scn 1920x1080 --gillum 16
 --shadow (depth 3), on 1/2/4/8 MI355X.  A "step" is one whole frame: every rank renders its
-interleaved row tiles with the HIP megakernel (C ABI, include/skr.h), the u8 tiles are gathered
-to rank 0 over RCCL and de-interleaved there.  Inputs (the SoA scene) are resident in HBM
-before the timed region.  `value` = radiance rays actually traced per second, whole job
-(rays = shade() calls with depth > 0, counted by the kernel itself; deterministic and
-partition-independent).  SURVEY.md §8d's closed form W*H*S*sum N^k is the full-tree upper
-bound (every ray hitting a sphere) and is reported beside it as `nominal_rays`.
+interleaved row tiles (C ABI, include/skr.h), the u8 tiles are gathered with ONE RCCL
+all-gather over xGMI and rank 0 de-interleaves them on the device — the whole step runs
+inside libskr (skr_comm_render_frame); torch.distributed only carries the 128-byte RCCL id
+and the barriers.  Inputs (the SoA scene) are resident in HBM before the timed region.
+`value` = radiance rays actually traced per second, whole job (rays = shade() calls with
+depth > 0, counted by the kernels themselves; deterministic and partition-independent).
+SURVEY.md §8d's closed form W*H*S*sum N^k is the full-tree upper bound (every ray hitting a
+sphere) and is reported beside it as `nominal_rays`.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -16,6 +18,7 @@ bound (every ray hitting a sphere) and is reported beside it as `nominal_rays`.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,6 +33,39 @@ KW = dict(gillum=16, shadow=True, depth=3, seed=20261004)
 TILE_ROWS = 8  # interleaved row tiles (cost is very non-uniform vertically: sky rows vs ground rows)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
+FLOP_PER_SPHERE_TEST, FLOP_PER_SHADED_HIT = 34, 150
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+# the files whose contents decide what the kernels move: the measured traffic is only reported for the exact sources it was measured on
+KERNEL_SOURCES = ["skele_raytracer_amd/csrc/render_nodes.hip", "skele_raytracer_amd/csrc/render_wave.hip", "skele_raytracer_amd/csrc/wave_common.h",
+                  "skele_raytracer_amd/csrc/shade_common.h", "skele_raytracer_amd/csrc/device_math.h", "skele_raytracer_amd/csrc/render_params.h"]
+DOMINANT = {"node_levels_v5": "skr_leaf_kernel2<false, false>", "level_queues_v4": "skr_leaf_kernel<false>", "parent_queue_v3": "skr_gi_kernel<3, 3, false>",
+            "wave_streaming_v2": "skr_wave_kernel<3, 3>"}
+
+
+def git_blob_hash(path):
+    """`git hash-object` of a file: sha1 of 'blob <len>\\0' + contents."""
+    with open(path, "rb") as f:
+        data = f.read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def source_hashes():
+    return {p: git_blob_hash(os.path.join(ROOT, p)) for p in KERNEL_SOURCES}
+
+
+def measured_traffic(variant):
+    """HBM bytes per frame over ALL kernels of the frame from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    this command (tools/pmc_traffic.sh; FETCH doubled per MI355X_MICROARCH.md) — or None when the kernel sources have changed since."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            tj = json.load(f)
+    except (OSError, ValueError):
+        return None, "no %s" % os.path.relpath(TRAFFIC_JSON, ROOT)
+    if tj.get("variant") != variant:
+        return None, "measured for kernel variant %s" % tj.get("variant")
+    if tj.get("sources") != source_hashes():
+        return None, "stale: the kernel sources have changed since the PMC passes (git blob hashes differ)"
+    return tj, None
 
 
 def reference_sample(orc):
@@ -77,24 +113,29 @@ def cpu_baseline():
             model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "unknown")
     except OSError:
         pass
+    host = os.cpu_count() or cores
     reference = reference_sample(orc)
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "cpu_model": model, "reference_1core": reference,
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "host_cores": host, "kind": "port", "cpu_model": model, "reference_1core": reference,
             "ms_per_frame": dt / frames * 1e3,
-            "sample": "oracle/liboracle.so (C restatement of the reference path, gcc -O2, OpenMP %d threads = this box's cgroup CPU "
-                      "quota), %d whole frames of the same workload: %d radiance rays in %.2f s" % (cores, frames, rays, dt)}
+            "sample": "oracle/liboracle.so (C restatement of the reference path, gcc -O2, OpenMP) on %d of this host's %d cores — the box's cgroup CPU quota; "
+                      "scaled to all %d cores the baseline would be ~%.0fx higher — %d whole frames of the same workload: %d radiance rays in %.2f s"
+                      % (cores, host, host, host / max(1, cores), frames, rays, dt)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=600)   # >= 1 s of frames at one GPU: the clock the chip settles at, not its first milliseconds
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-gather", action="store_true", help="the round-1 frame step (torch.distributed all_gather + torch de-interleave) instead of libskr's")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     import skele_raytracer_amd as skr
+    from skele_raytracer_amd import binding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -123,22 +164,35 @@ def main():
     scene = skr.parse_scene(SCENE)
     r = skr.Renderer(scene, local_rank)
     opt = skr.Options(W, H, **KW)
-    sharder = FrameSharder(W, H, TILE_ROWS, rank, world, dev)  # interleaved row tiles + one RCCL all-gather
-    k_max = sharder.k_max
     stream = torch.cuda.current_stream(dev)
-    ev_box = [None]
+    k_max = binding.shard_tiles_per_rank(H, TILE_ROWS, world)
 
-    def render_into(buf):
-        ev = ev_box[0]
-        if ev:
-            ev[0].record(stream)
-        r.render_tiles_into(opt, TILE_ROWS, rank, world, buf.data_ptr(), None, stream.cuda_stream)
-        if ev:
-            ev[1].record(stream)
+    # the frame step: libskr's own (RCCL inside the library) unless it cannot be set up — then, and on request, round 1's
+    comm, native_note = None, None
+    if not args.torch_gather and not rehearsal:
+        try:
+            uid = None
+            if world > 1:
+                t = torch.zeros(binding.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    t.copy_(torch.from_numpy(np.frombuffer(binding.comm_unique_id(), dtype=np.uint8).copy()))
+                dist.broadcast(t, 0)
+                uid = bytes(t.cpu().numpy().tobytes())
+            comm = binding.Comm(r, rank, world, uid)
+        except skr.SkrError as e:
+            native_note = "libskr's RCCL step unavailable (%s): torch.distributed all_gather used" % str(e)[:160]
+    if world > 1:  # every rank takes the same path
+        ok = torch.tensor([1 if comm is not None else 0], device=dev) if not rehearsal else torch.tensor([0])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            comm = None
+    sharder = None if comm is not None else FrameSharder(W, H, TILE_ROWS, rank, world, dev)
 
-    def step(ev=None):
-        ev_box[0] = ev
-        sharder.step(render_into)
+    def step():
+        if comm is not None:
+            comm.render_frame(opt, TILE_ROWS, stream.cuda_stream)
+        else:
+            sharder.step(lambda buf: r.render_tiles_into(opt, TILE_ROWS, rank, world, buf.data_ptr(), None, stream.cuda_stream))
 
     def sync():
         if world > 1:
@@ -148,89 +202,115 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    r.counters(reset=True)
-    r.kernel_timing(True)
-    r.kernel_ms()  # drop the warm-up launches
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    r.work(reset=True)
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(events[i])
+    for _ in range(args.steps):
+        step()
     sync()
     dt = time.perf_counter() - t0
 
     variant = r.kernel_variant()
-    queued = r.last_parent_count() if variant in ("parent_queue_v3", "level_queues_v4") else 0  # before the counters are reset
-    level1 = r.last_level1_count() if variant == "level_queues_v4" else 0
-    cnt = r.counters(reset=True)
-    pipeline_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)  # everything this rank enqueues per frame before the collective
-    kernel_ms, timed_launches = r.kernel_ms()                                      # the dominant kernel alone (HIP events on its stream)
-    stats = torch.tensor([dt, float(cnt["radiance_rays"]), float(cnt["shadow_rays"]), float(cnt["sphere_hits"]), kernel_ms, pipeline_ms],
-                         dtype=torch.float64, device=dev)
+    queued = r.last_parent_count()
+    level1 = r.last_level1_count()
+    cnt = r.work(reset=True)
+    # the dominant kernel alone: HIP events on its stream around every launch of a short extra pass (not in the timed region)
+    r.kernel_timing(True)
+    r.kernel_ms()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n_probe = min(args.steps, 50)
+    e0.record(stream)
+    for _ in range(n_probe):
+        r.render_tiles_into(opt, TILE_ROWS, rank, world, r_probe_buf(torch, dev, k_max).data_ptr(), None, stream.cuda_stream)
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    kernel_ms, _ = r.kernel_ms()
+    r.kernel_timing(False)
+    pipeline_ms = e0.elapsed_time(e1) / n_probe  # everything this rank enqueues per frame before the collective
+    r.work(reset=True)
+
+    stats = torch.tensor([dt, float(cnt["radiance_rays"]), float(cnt["shadow_rays"]), float(cnt["sphere_hits"]), float(cnt["sphere_tests"]), kernel_ms, pipeline_ms],
+                         dtype=torch.float64, device=dev if not rehearsal else "cpu")
     if world > 1:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        dt, kernel_ms, pipeline_ms = float(mx[0]), float(mx[4]), float(mx[5])
-        rays, shadow, hits = float(sm[1]), float(sm[2]), float(sm[3])
+        dt, kernel_ms, pipeline_ms = float(mx[0]), float(mx[5]), float(mx[6])
+        rays, shadow, hits, tests = float(sm[1]), float(sm[2]), float(sm[3]), float(sm[4])
     else:
-        rays, shadow, hits = float(stats[1]), float(stats[2]), float(stats[3])
+        rays, shadow, hits, tests = float(stats[1]), float(stats[2]), float(stats[3]), float(stats[4])
 
     if rank == 0:
-        rays_per_frame = rays / args.steps
+        n = args.steps
+        rays_per_frame = rays / n
+        ms_per_step = dt / n * 1e3
         info = scene.info
-        # algorithmic HBM bytes of one launch of the dominant kernel on this rank:
-        #  single megakernel: its share of the u8 framebuffer + one read of the scene
-        #  parent-queue pipeline: the GI kernel reads one 64-byte record per primary hit and writes that pixel (3 B)
+        # ---- HBM roofline, as SURVEY.md §8(d) defines it: the algorithm's compulsory bytes per frame — the u8 framebuffer out and one read of
+        # the scene — over the frame time.  (0.011 B per nominal ray x the rays of a frame.)  Structurally ~4e-4 of peak: this path is not
+        # HBM-bound; what the pipeline itself moves between its kernels is `pipeline_bytes`, what the counters saw is `traffic`.
         scene_bytes = info.n_spheres * 64 + info.n_point_lights * 32 + info.n_triangles * 48
-        frame_bytes = W * min(H, k_max * TILE_ROWS) * 3
-        n_parents = queued
-        if level1:   # leaf kernel of the level-queue pipeline: one 64-byte record read and one 12-byte slot written per level-1 hit
-            launch_bytes = level1 * (64 + 12) + scene_bytes
-        else:        # GI kernel of the parent-queue pipeline, or the single megakernel
-            launch_bytes = (n_parents * (64 + 3) + scene_bytes) if n_parents else (frame_bytes + scene_bytes)
-        achieved_gbs = launch_bytes / (kernel_ms * 1e-3) / 1e9
-        # HBM bytes per launch from PMC counters cannot be collected from inside this process; the figure of the
-        # last committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command is reported (N=1 only)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-                tj = json.load(f)
-            if world == 1 and tj.get("variant") == r.kernel_variant():
-                traffic = tj["traffic_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
-        # algorithmic flops: 34 flop per ray-sphere test; per radiance ray n_sph tests,
-        # per shadow ray at most n_sph (early-out ignored => upper bound), ~150 flop shading per hit
-        alg_flop = (rays_per_frame * info.n_spheres + shadow / args.steps * info.n_spheres) * 34 + hits / args.steps * 150
+        alg_bytes = W * H * 3 + scene_bytes
+        achieved_gbs = alg_bytes / (ms_per_step * 1e-3) / 1e9
+        # the node pipeline's own records (one band = the frame): 48 B per level-0 node written and read three times, 32 B per level-1 record
+        # written and read, 4 B per child index word written and read, 12 B per record result written and read
+        N = KW["gillum"]
+        pipeline_bytes = (queued * (48 * 4 + 2 * 4 * N) + level1 * (2 * 32 + 3 * 12)) if variant == "node_levels_v5" else None
+        tj, why = measured_traffic(variant) if world == 1 else (None, "measured at N = 1 only")
+        traffic = tj["traffic_bytes_per_frame"] if tj else None
+        # ---- FP32-VALU roofline: the flops the reference's algorithm needs for this frame — every ray-sphere test it would run (early-outs of the
+        # shadow walks counted by the kernels, asserted equal to the oracle's count) and every shaded hit — over the frame time, per GPU
+        alg_flop = tests / n * FLOP_PER_SPHERE_TEST + hits / n * FLOP_PER_SHADED_HIT
+        valu_tflops = alg_flop / (ms_per_step * 1e-3) / 1e12 / world
         out = {
             "metric": "Mrays/sec + frame ms, 1920x1080 gillum=16 spheres2.scn",
-            "value": rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "value": rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": n, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "reference scene file scenes/spheres2.scn (spherical_fog line skipped: UB in the reference)",
             "config": {"workload": "scenes/spheres2.scn 1920x1080 --gillum 16 --shadow --depth 3 (BASELINE.json configs[2])",
                        "rays_per_frame": rays_per_frame, "nominal_rays": skr.radiance_ray_count(opt),
-                       "nominal_mrays_per_s": skr.radiance_ray_count(opt) * args.steps / dt / 1e6,
-                       "shadow_rays_per_frame": shadow / args.steps, "partition": "interleaved %d-row tiles, rank = tile %% %d" % (TILE_ROWS, world),
-                       "gather": ("REHEARSAL on one GPU over gloo - not a measurement" if rehearsal else "RCCL all-gather of the u8 tile buffers, rank 0 de-interleaves") if world > 1 else "none (1 GPU)",
-                       "kernel": r.kernel_variant(), "seed": KW["seed"]},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; FETCH doubled per the gfx950 note)" if traffic else None,
-                         "kernel": {"level_queues_v4": "skr_leaf_kernel<false>", "parent_queue_v3": "skr_gi_kernel<3, 3, false>", "wave_streaming_v2": "skr_wave_kernel<3, 3>"}.get(r.kernel_variant(), "skr_render_kernel<3>"), "kernel_ms": kernel_ms, "render_ms": pipeline_ms, "algorithmic_bytes_per_launch": launch_bytes, "frame_bytes": frame_bytes, "queued_parents": n_parents, "queued_level1_hits": level1,
-                         "note": "algorithmic HBM bytes of the dominant kernel: the level-1 hit records it reads (64 B) and the slots it writes (12 B) + ~1 KB of scene; this path is FP32-VALU bound, see roofline_valu"},
-            "roofline_valu": {"bound": "fp32_valu", "achieved": alg_flop / (kernel_ms * 1e-3) / 1e12 / world * 1.0,
-                              "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": alg_flop / (kernel_ms * 1e-3) / 1e12 / world / VALU_PEAK_TFLOPS,
-                              "note": "algorithmic flops (34/sphere test, 150/shaded hit; shadow early-outs ignored) per GPU / peak FP32 vector"},
+                       "nominal_mrays_per_s": skr.radiance_ray_count(opt) * n / dt / 1e6,
+                       "shadow_rays_per_frame": shadow / n, "sphere_tests_per_frame": tests / n, "shaded_hits_per_frame": hits / n,
+                       "partition": "interleaved %d-row tiles, rank = tile %% %d" % (TILE_ROWS, world),
+                       "frame_step": ("REHEARSAL on one GPU over gloo - not a measurement" if rehearsal else
+                                      ("libskr skr_comm_render_frame: tiles -> ncclAllGather (RCCL, in the library) -> de-interleave kernel on rank 0" if comm is not None else
+                                       "torch.distributed all_gather_into_tensor of the u8 tile buffers, rank 0 de-interleaves (torch)")) if world > 1
+                                     else ("libskr skr_comm_render_frame (1 GPU: tiles + de-interleave kernel, no collective)" if comm is not None else "skr_render_tiles"),
+                       "frame_step_note": native_note, "kernel": variant, "seed": KW["seed"]},
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                         "traffic_per_kernel": tj.get("per_kernel") if tj else None,
+                         "traffic_source": ("profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over every kernel of the frame, FETCH doubled "
+                                            "per the gfx950 note; keyed by the git blob hashes of the kernel sources") if traffic else why,
+                         "algorithmic_bytes_per_frame": alg_bytes, "pipeline_bytes": pipeline_bytes,
+                         "kernel": DOMINANT.get(variant, "skr_render_kernel<3>"), "kernel_ms": kernel_ms, "render_ms": pipeline_ms,
+                         "level0_nodes": queued, "level1_records": level1,
+                         "note": "SURVEY.md 8(d): algorithmic bytes = W*H*3 + scene per frame, over ms_per_step; this path is bound by FP32 VALU issue, not by HBM (roofline_valu); "
+                                 "kernel_ms = the dominant kernel's mean launch duration (HIP events on its stream, a separate untimed pass)"},
+            "roofline_valu": {"bound": "fp32_valu", "achieved": valu_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu_tflops / VALU_PEAK_TFLOPS,
+                              "algorithmic_gflop_per_frame": alg_flop / 1e9,
+                              "note": "frame flops over frame time per GPU: %d flop per ray-sphere test the reference runs (shadow walks stop at their first occluder: counted, "
+                                      "not assumed), %d per shaded hit (SURVEY.md 8d); the spec forbids FMA contraction, so 1/2 of the FMA peak is the ceiling of this instruction stream"
+                                      % (FLOP_PER_SPHERE_TEST, FLOP_PER_SHADED_HIT)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+_probe = {}
+
+
+def r_probe_buf(torch, dev, k_max):
+    if "b" not in _probe:
+        _probe["b"] = torch.zeros((k_max * TILE_ROWS, W, 3), dtype=torch.uint8, device=dev)
+    return _probe["b"]
 
 
 if __name__ == "__main__":

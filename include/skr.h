@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SKR_ABI_VERSION 1
+#define SKR_ABI_VERSION 2
 
 typedef enum {
 	SKR_OK = 0,
@@ -132,19 +132,62 @@ int skr_render_rows(skr_renderer *r, const skr_options *opt, uint32_t y0, uint32
  * out[0] radiance rays = shade() calls with depth > 0, out[1] sphere hits shaded,
  * out[2] shadow rays (one per light per hit; the reference casts each twice). */
 int skr_renderer_read_counters(skr_renderer *r, uint64_t out[3], int reset);
+/* The same plus out[3] = ray-sphere tests as the reference runs them: every sphere for a radiance ray
+ * (raytrace.h:152-165), up to and including the first occluder for a shadow ray (utils.h:52-55).  The
+ * numerator of bench.py's FP32-VALU roofline; asserted equal to the oracle's count. */
+int skr_renderer_read_work(skr_renderer *r, uint64_t out[4], int reset);
+/* The SKR_* development switches (kernel variant, budgets: DESIGN.md) are read from the environment
+ * once, at skr_renderer_create; this reads them again (tests and A/B tools change them between frames). */
+int skr_renderer_reload_switches(skr_renderer *r);
 /* Time the dominant kernel of each launch with HIP events recorded on the launch stream (off by
  * default).  skr_renderer_kernel_ms() waits for the launches made since the last call and returns
  * their mean duration in ms and their number: what bench.py's roofline is computed from. */
 int skr_renderer_kernel_timing(skr_renderer *r, int enable);
 int skr_renderer_kernel_ms(skr_renderer *r, float *mean_ms, int32_t *launches);
-/* Number of primary sphere hits the last launch queued for the --gillum kernel (0 if that launch did not
- * use the parent queue); synchronous.  bench.py sizes the GI kernel's algorithmic HBM bytes with it. */
+/* Number of primary sphere hits the last launch (its last band) queued as level-0 nodes / parents for the
+ * --gillum kernels (0 if that launch had no --gillum tree); synchronous. */
 int skr_renderer_last_parent_count(skr_renderer *r, uint32_t *n);
-/* Number of level-1 sphere hits the last launch (its last band) queued for the leaf kernel of the level-queue
- * pipeline (0 for the other kernel variants); synchronous. */
+/* Number of level-1 sphere hit records the last launch (its last band) queued (node and level-queue pipelines;
+ * 0 for the other kernel variants and at depth 2); synchronous. */
 int skr_renderer_last_level1_count(skr_renderer *r, uint32_t *n);
 /* Whole frame into HOST memory (W*H*3 bytes), synchronous; what the CLI uses. */
 int skr_render_frame_host(skr_renderer *r, const skr_options *opt, uint8_t *h_rgb, float *kernel_ms);
+
+/* ---- multi-GPU: the frame sharded over the GPUs of one node ----
+ * Replaces the reference's only parallel entry, `generate_rays_parallel` (main.cpp:19-104: `#pragma omp parallel for`
+ * over the rows at :33, dispatched at main.cpp:402-410) — the reference has no distributed path.
+ * The framebuffer is cut into tiles of tile_rows rows, tile t belongs to rank t mod G; every rank renders its tiles
+ * (skr_render_tiles, first_tile = rank, tile_stride = G) straight into its slot of a gather buffer, ONE RCCL
+ * all-gather over xGMI brings the slots together and rank 0 de-interleaves on the device.  The image does not
+ * depend on G.  RCCL is bound at run time; skr_rccl_available() says whether it could be. */
+int skr_rccl_available(void);
+/* (a) ONE process, N devices (ncclCommInitAll; a renderer, a stream and a worker thread per device).
+ * devices == NULL: devices 0 .. n_devices-1.  What `raytracer --gpus N` uses. */
+typedef struct skr_multi skr_multi;
+int skr_multi_create(const skr_scene *scene, int n_devices, const int *devices, skr_multi **out);
+void skr_multi_destroy(skr_multi *m);
+int skr_multi_device_count(const skr_multi *m);
+skr_renderer *skr_multi_renderer(skr_multi *m, int i); /* device i's renderer (counters, timing); owned by m */
+/* Synchronous.  *d_frame: the W*H*3 frame in device 0's memory (owned by m, valid until the next call);
+ * frame_ms: first launch to de-interleaved frame, on the root's stream. */
+int skr_multi_render_frame(skr_multi *m, const skr_options *opt, uint32_t tile_rows, uint8_t **d_frame, float *frame_ms);
+int skr_multi_render_frame_host(skr_multi *m, const skr_options *opt, uint32_t tile_rows, uint8_t *h_rgb, float *frame_ms);
+/* (b) one process PER device (torchrun, mpirun): rank 0 makes an id, the caller broadcasts it by whatever transport
+ * it has, every rank creates its communicator on its renderer's device.  id == NULL with world == 1: no RCCL at all. */
+#define SKR_COMM_ID_BYTES 128
+typedef struct skr_comm skr_comm;
+int skr_comm_unique_id(uint8_t id[SKR_COMM_ID_BYTES]);
+int skr_comm_create(skr_renderer *r, int device, const uint8_t id[SKR_COMM_ID_BYTES], int rank, int world, skr_comm **out);
+void skr_comm_destroy(skr_comm *c);
+/* Asynchronous on `stream`: this rank's tiles, the all-gather, rank 0's de-interleave.  *d_frame: rank 0's finished
+ * frame (device memory owned by c; NULL on the other ranks) once the stream has drained. */
+int skr_comm_render_frame(skr_comm *c, const skr_options *opt, uint32_t tile_rows, uint8_t **d_frame, void *stream);
+/* Rank 0: waits for `stream` and copies that frame to host memory (W*H*3 bytes). */
+int skr_comm_frame_to_host(skr_comm *c, uint8_t *h_rgb, void *stream);
+/* The partition itself (host logic, no GPU): padded tiles per rank, and the de-interleave of a rank-major gathered
+ * buffer [world][tiles_per_rank * tile_rows][W*3] into frame[H][W*3]. */
+uint32_t skr_shard_tiles_per_rank(int32_t height, uint32_t tile_rows, uint32_t world);
+int skr_shard_deinterleave_host(const uint8_t *gathered, uint8_t *frame, int32_t width, int32_t height, uint32_t tile_rows, uint32_t world);
 
 /* ---- image file: replaces the inline writer main.cpp:199-211 ---- */
 int skr_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb);

@@ -11,8 +11,11 @@ EXPORTED_SYMBOLS = [
     "skr_scene_create_from_scn", "skr_scene_create_from_arrays", "skr_scene_destroy", "skr_scene_get_info",
     "skr_scene_get_arrays", "skr_scene_get_culling", "skr_options_default", "skr_radiance_ray_count", "skr_device_count",
     "skr_renderer_create", "skr_renderer_destroy", "skr_render_tiles", "skr_tile_count", "skr_render_rows",
-    "skr_renderer_read_counters", "skr_renderer_kernel_timing", "skr_renderer_kernel_ms", "skr_renderer_last_parent_count", "skr_renderer_last_level1_count", "skr_render_frame_host", "skr_write_ppm", "skr_last_error",
+    "skr_renderer_read_counters", "skr_renderer_read_work", "skr_renderer_reload_switches", "skr_renderer_kernel_timing", "skr_renderer_kernel_ms", "skr_renderer_last_parent_count", "skr_renderer_last_level1_count", "skr_render_frame_host", "skr_write_ppm", "skr_last_error",
     "skr_kernel_variant", "skr_debug_eval",
+    "skr_rccl_available", "skr_multi_create", "skr_multi_destroy", "skr_multi_device_count", "skr_multi_renderer", "skr_multi_render_frame",
+    "skr_multi_render_frame_host", "skr_comm_unique_id", "skr_comm_create", "skr_comm_destroy", "skr_comm_render_frame", "skr_comm_frame_to_host",
+    "skr_shard_tiles_per_rank", "skr_shard_deinterleave_host",
 ]
 
 
@@ -78,6 +81,8 @@ def lib():
     L.skr_tile_count.restype = C.c_uint32
     L.skr_render_rows.argtypes = [vp, C.POINTER(COptions), C.c_uint32, C.c_uint32, vp, vp, vp]
     L.skr_renderer_read_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+    L.skr_renderer_read_work.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+    L.skr_renderer_reload_switches.argtypes = [vp]
     L.skr_renderer_kernel_timing.argtypes = [vp, C.c_int]
     L.skr_renderer_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     L.skr_renderer_last_parent_count.argtypes = [vp, C.POINTER(C.c_uint32)]
@@ -87,6 +92,24 @@ def lib():
     L.skr_last_error.restype = C.c_char_p
     L.skr_kernel_variant.restype = C.c_char_p
     L.skr_debug_eval.argtypes = [C.c_int, vp, vp, C.c_uint32, vp]
+    L.skr_rccl_available.restype = C.c_int
+    L.skr_multi_create.argtypes = [vp, C.c_int, vp, C.POINTER(vp)]
+    L.skr_multi_destroy.argtypes = [vp]
+    L.skr_multi_destroy.restype = None
+    L.skr_multi_device_count.argtypes = [vp]
+    L.skr_multi_renderer.argtypes = [vp, C.c_int]
+    L.skr_multi_renderer.restype = vp
+    L.skr_multi_render_frame.argtypes = [vp, C.POINTER(COptions), C.c_uint32, C.POINTER(vp), C.POINTER(C.c_float)]
+    L.skr_multi_render_frame_host.argtypes = [vp, C.POINTER(COptions), C.c_uint32, vp, C.POINTER(C.c_float)]
+    L.skr_comm_unique_id.argtypes = [vp]
+    L.skr_comm_create.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.skr_comm_destroy.argtypes = [vp]
+    L.skr_comm_destroy.restype = None
+    L.skr_comm_render_frame.argtypes = [vp, C.POINTER(COptions), C.c_uint32, C.POINTER(vp), vp]
+    L.skr_comm_frame_to_host.argtypes = [vp, vp, vp]
+    L.skr_shard_tiles_per_rank.argtypes = [C.c_int32, C.c_uint32, C.c_uint32]
+    L.skr_shard_tiles_per_rank.restype = C.c_uint32
+    L.skr_shard_deinterleave_host.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32]
     _lib = L
     return L
 
@@ -199,6 +222,19 @@ class Renderer:
         h = C.c_void_p()
         _check(lib().skr_renderer_create(scene.h, device, C.byref(h)), "skr_renderer_create")
         self.h = h
+        self._env = self._switch_env()
+
+    @staticmethod
+    def _switch_env():
+        return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("SKR_")))
+
+    def _sync_switches(self):
+        """libskr reads its SKR_* development switches once per renderer; tests and A/B tools change them between
+        frames, so the binding asks for a re-read when this process's environment has changed since."""
+        env = self._switch_env()
+        if env != self._env:
+            _check(lib().skr_renderer_reload_switches(self.h), "skr_renderer_reload_switches")
+            self._env = env
 
     def close(self):
         if getattr(self, "h", None):
@@ -212,6 +248,7 @@ class Renderer:
 
     def render_tiles_into(self, opt, tile_rows, first_tile, tile_stride, rgb_ptr, rgbf_ptr=None, stream=None):
         """Enqueue the megakernel for this partition; pointers are raw device addresses."""
+        self._sync_switches()
         _check(lib().skr_render_tiles(self.h, C.byref(opt.c), tile_rows, first_tile, tile_stride, rgb_ptr, rgbf_ptr,
                                       stream), "skr_render_tiles")
 
@@ -236,6 +273,7 @@ class Renderer:
         dev = torch.device("cuda", self.device)
         rgb = torch.zeros((y1 - y0, opt.width, 3), dtype=torch.uint8, device=dev)
         rgbf = torch.zeros((y1 - y0, opt.width, 3), dtype=torch.float32, device=dev) if want_float else None
+        self._sync_switches()
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             _check(lib().skr_render_rows(self.h, C.byref(opt.c), y0, y1, rgb.data_ptr(),
@@ -246,6 +284,12 @@ class Renderer:
         out = (C.c_uint64 * 3)()
         _check(lib().skr_renderer_read_counters(self.h, out, int(reset)), "skr_renderer_read_counters")
         return {"radiance_rays": int(out[0]), "sphere_hits": int(out[1]), "shadow_rays": int(out[2])}
+
+    def work(self, reset=True):
+        """counters() plus sphere_tests (include/skr.h skr_renderer_read_work)."""
+        out = (C.c_uint64 * 4)()
+        _check(lib().skr_renderer_read_work(self.h, out, int(reset)), "skr_renderer_read_work")
+        return {"radiance_rays": int(out[0]), "sphere_hits": int(out[1]), "shadow_rays": int(out[2]), "sphere_tests": int(out[3])}
 
     def kernel_timing(self, enable=True):
         _check(lib().skr_renderer_kernel_timing(self.h, int(enable)), "skr_renderer_kernel_timing")
@@ -269,6 +313,94 @@ class Renderer:
     @staticmethod
     def kernel_variant():
         return (lib().skr_kernel_variant() or b"").decode()
+
+
+COMM_ID_BYTES = 128
+
+
+def rccl_available():
+    return bool(lib().skr_rccl_available())
+
+
+def comm_unique_id():
+    """An RCCL id (rank 0 makes it; the caller broadcasts the 128 bytes by whatever transport it has)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(lib().skr_comm_unique_id(buf), "skr_comm_unique_id")
+    return bytes(buf)
+
+
+class Comm:
+    """One rank of the native frame step (include/skr.h skr_comm_*): this rank's tiles, ONE RCCL all-gather, rank 0's
+    de-interleave on the device — all inside libskr, enqueued on the caller's stream."""
+
+    def __init__(self, renderer, rank, world, unique_id=None):
+        self.renderer, self.rank, self.world = renderer, rank, world
+        h = C.c_void_p()
+        idbuf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id) if unique_id is not None else None
+        _check(lib().skr_comm_create(renderer.h, renderer.device, idbuf, rank, world, C.byref(h)), "skr_comm_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().skr_comm_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def render_frame(self, opt, tile_rows, stream=None):
+        """Enqueue one frame; returns the device address of rank 0's finished frame (None on the other ranks)."""
+        self.renderer._sync_switches()
+        d = C.c_void_p()
+        _check(lib().skr_comm_render_frame(self.h, C.byref(opt.c), tile_rows, C.byref(d), stream), "skr_comm_render_frame")
+        return d.value
+
+    def frame_to_host(self, opt, stream=None):
+        """Rank 0: the frame of the last render_frame as a numpy array (waits for the stream)."""
+        rgb = np.zeros((opt.height, opt.width, 3), np.uint8)
+        _check(lib().skr_comm_frame_to_host(self.h, rgb.ctypes.data, stream), "skr_comm_frame_to_host")
+        return rgb
+
+
+class Multi:
+    """One process, N devices (include/skr.h skr_multi_*)."""
+
+    def __init__(self, scene, n_devices):
+        h = C.c_void_p()
+        _check(lib().skr_multi_create(scene.h, n_devices, None, C.byref(h)), "skr_multi_create")
+        self.h, self.n = h, n_devices
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().skr_multi_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def render_frame_host(self, opt, tile_rows=8):
+        rgb = np.zeros((opt.height, opt.width, 3), np.uint8)
+        ms = C.c_float()
+        _check(lib().skr_multi_render_frame_host(self.h, C.byref(opt.c), tile_rows, rgb.ctypes.data, C.byref(ms)), "skr_multi_render_frame_host")
+        return rgb, ms.value
+
+    def counters(self, reset=True):
+        tot = {"radiance_rays": 0, "sphere_hits": 0, "shadow_rays": 0}
+        for i in range(self.n):
+            out = (C.c_uint64 * 3)()
+            _check(lib().skr_renderer_read_counters(lib().skr_multi_renderer(self.h, i), out, int(reset)), "skr_renderer_read_counters")
+            for k, name in enumerate(tot):
+                tot[name] += int(out[k])
+        return tot
+
+
+def shard_tiles_per_rank(height, tile_rows, world):
+    return int(lib().skr_shard_tiles_per_rank(height, tile_rows, world))
+
+
+def shard_deinterleave_host(gathered, width, height, tile_rows, world):
+    g = np.ascontiguousarray(gathered, np.uint8)
+    out = np.zeros((height, width, 3), np.uint8)
+    _check(lib().skr_shard_deinterleave_host(g.ctypes.data, out.ctypes.data, width, height, tile_rows, world), "skr_shard_deinterleave_host")
+    return out
 
 
 def debug_eval(op, inp, out_words_per_record, device=0):

@@ -20,6 +20,7 @@ void skr_queue_scratch_bytes(const RenderParams &p, size_t *parent_bytes, size_t
 bool skr_levels_scratch_bytes(RenderParams &p, size_t *p1_bytes, size_t *slot1_bytes);
 bool skr_nodes_selected(const RenderParams &p);
 size_t skr_nodes_scratch_bytes(const RenderParams &p);
+bool skr_nodes_counter_layout(const RenderParams &p, size_t *off_ctr, size_t *level_words, int *levels);
 
 static thread_local const char *g_variant = "none";
 
@@ -52,11 +53,31 @@ struct skr_renderer {
 	size_t parents_cap = 0;
 	float *d_acc = nullptr;
 	size_t acc_cap = 0;
+	uint8_t *d_frame = nullptr; // skr_render_frame_host
+	size_t frame_cap = 0;
+	hipEvent_t frame_e0 = nullptr, frame_e1 = nullptr;
 	// skr_renderer_kernel_ms: event pairs around the dominant kernel of recent launches
+	SkrSwitches sw; // the SKR_* development switches, read once (load_switches)
+	RenderParams last_p{}; // the launch last enqueued (skr_renderer_last_*_count)
+	bool last_nodes = false;
 	bool timing = false;
 	std::vector<SkrTimingHook> timed;
 	std::vector<SkrTimingHook> free_pairs;
 };
+
+static void load_switches(SkrSwitches &sw)
+{
+	sw = SkrSwitches();
+	if(const char *e = getenv("SKR_PIPELINE"))
+		sw.pipeline = !strcmp(e, "nodes") ? SKR_PIPE_NODES : !strcmp(e, "levels") ? SKR_PIPE_LEVELS : !strcmp(e, "queue") ? SKR_PIPE_QUEUE : !strcmp(e, "mega") ? SKR_PIPE_MEGA : SKR_PIPE_OTHER;
+	if(const char *e = getenv("SKR_KERNEL")) sw.kernel_v1 = !strcmp(e, "v1");
+	if(const char *e = getenv("SKR_OCC")) sw.occ = atoi(e) >= 3 ? 3 : 2;
+	if(const char *e = getenv("SKR_TILE")) sw.tile = (atoi(e) == 64 || atoi(e) == 32 || atoi(e) == 16) ? atoi(e) : 0;
+	sw.no_cones = getenv("SKR_NO_CONES") != nullptr;
+	sw.no_cull = getenv("SKR_NO_CULL") != nullptr;
+	if(const char *e = getenv("SKR_LEVELS_BUDGET_MB")) sw.budget_mb = atoi(e) > 0 ? atoi(e) : 1;
+	if(const char *e = getenv("SKR_UNIT_STRIDE")) sw.unit_strided = atoi(e) != 0;
+}
 
 extern "C" {
 
@@ -90,6 +111,7 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 		return SKR_ERR_NO_DEVICE;
 	}
 	skr_renderer *r = new skr_renderer();
+	load_switches(r->sw);
 	r->device = device;
 	r->info = scene->info;
 	r->lds_limit = (int) prop.sharedMemPerBlock;
@@ -143,6 +165,9 @@ void skr_renderer_destroy(skr_renderer *r)
 	if(r->d_levels) (void) hipFree(r->d_levels);
 	if(r->d_nodes) (void) hipFree(r->d_nodes);
 	if(r->d_acc) (void) hipFree(r->d_acc);
+	if(r->d_frame) (void) hipFree(r->d_frame);
+	if(r->frame_e0) (void) hipEventDestroy(r->frame_e0);
+	if(r->frame_e1) (void) hipEventDestroy(r->frame_e1);
 	for(SkrTimingHook &h : r->timed) { (void) hipEventDestroy(h.start); (void) hipEventDestroy(h.stop); }
 	for(SkrTimingHook &h : r->free_pairs) { (void) hipEventDestroy(h.start); (void) hipEventDestroy(h.stop); }
 	delete r;
@@ -192,6 +217,7 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	SKR_HIP(hipSetDevice(r->device));
 
 	RenderParams p{};
+	p.sw = r->sw;
 	p.width = opt->width;
 	p.height = opt->height;
 	p.tile_rows = tile_rows;
@@ -222,7 +248,7 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.tris = r->d_blob + r->off_tris;
 	p.tri_chunks = r->d_blob + r->off_chunks;
 	p.tri_chunk_size = r->chunk_size;
-	p.tri_cones = (r->cones && !getenv("SKR_NO_CONES")) ? 1 : 0;
+	p.tri_cones = (r->cones && !r->sw.no_cones) ? 1 : 0;
 	{ // pick the tightest set of chunk spheres whose |d| bound covers this frame's camera rays (GI children stay below 4,
 	  // the smallest bound): primary directions are dir + u right + v up (main.cpp:154-155)
 		auto len3 = [](const float *v) { return std::sqrt((double) v[0] * v[0] + (double) v[1] * v[1] + (double) v[2] * v[2]); };
@@ -231,7 +257,7 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 		const double bound[SKR_CULL_LEVELS] = SKR_CULL_DMAX_LIST;
 		int level = 0;
 		while(level < SKR_CULL_LEVELS && !(dmax < bound[level])) level++;
-		p.n_tri_chunks = (level < SKR_CULL_LEVELS && !getenv("SKR_NO_CULL")) ? r->n_chunks : 0;
+		p.n_tri_chunks = (level < SKR_CULL_LEVELS && !r->sw.no_cull) ? r->n_chunks : 0;
 		if(p.n_tri_chunks) p.tri_chunks += (size_t) level * r->chunk_stride;
 	}
 	p.monte_carlo = opt->monte_carlo ? 1 : 0;
@@ -348,6 +374,8 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 			SKR_HIP(hipEventCreate(&hook.stop));
 		}
 	}
+	r->last_p = p;
+	r->last_nodes = nodes_path;
 	SKR_HIP(skr_launch_render(p, (hipStream_t) stream, &g_variant, r->timing ? &hook : nullptr));
 	if(r->timing) r->timed.push_back(hook);
 	return SKR_OK;
@@ -375,6 +403,13 @@ int skr_render_rows(skr_renderer *r, const skr_options *opt, uint32_t y0, uint32
 		b = t;
 	}
 	return render_impl(r, opt, a, y0 / a, 1, (y1 - y0) / a, d_rgb, d_rgbf, stream);
+}
+
+int skr_renderer_reload_switches(skr_renderer *r)
+{
+	if(!r) return SKR_ERR_ARG;
+	load_switches(r->sw);
+	return SKR_OK;
 }
 
 int skr_renderer_kernel_timing(skr_renderer *r, int enable)
@@ -405,10 +440,32 @@ int skr_renderer_kernel_ms(skr_renderer *r, float *mean_ms, int32_t *launches)
 	return SKR_OK;
 }
 
+// node pipeline: records of level `level` in the band last rendered (level 0: its level-0 nodes)
+static int nodes_level_count(skr_renderer *r, int level, uint32_t *n)
+{
+	size_t off = 0, words = 0;
+	int levels = 0;
+	*n = 0;
+	if(!skr_nodes_counter_layout(r->last_p, &off, &words, &levels) || level >= levels) return SKR_OK;
+	const uint32_t *ctr = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(r->d_nodes) + off);
+	if(level == 0)
+	{
+		SKR_HIP(hipMemcpy(n, ctr, sizeof(uint32_t), hipMemcpyDeviceToHost));
+		return SKR_OK;
+	}
+	std::vector<uint32_t> h((size_t) SKR_P1_REGIONS * SKR_PULL_STRIDE);
+	SKR_HIP(hipMemcpy(h.data(), ctr + SKR_PULL_STRIDE + words * (size_t) level, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	uint64_t total = 0;
+	for(uint32_t k = 0; k < SKR_P1_REGIONS; k++) total += h[(size_t) SKR_PULL_STRIDE * k];
+	*n = (uint32_t) total;
+	return SKR_OK;
+}
+
 int skr_renderer_last_parent_count(skr_renderer *r, uint32_t *n)
 {
 	if(!r || !n) return SKR_ERR_ARG;
 	SKR_HIP(hipSetDevice(r->device));
+	if(r->last_nodes) return nodes_level_count(r, 0, n);
 	SKR_HIP(hipMemcpy(n, r->d_counters + (size_t) SKR_COUNTER_SHARDS * 4 + 8, sizeof(uint32_t), hipMemcpyDeviceToHost));
 	return SKR_OK;
 }
@@ -417,6 +474,7 @@ int skr_renderer_last_level1_count(skr_renderer *r, uint32_t *n)
 {
 	if(!r || !n) return SKR_ERR_ARG;
 	SKR_HIP(hipSetDevice(r->device));
+	if(r->last_nodes) return nodes_level_count(r, 1, n);
 	std::vector<uint32_t> h((size_t) (SKR_PULL_QUEUES + 1 + SKR_P1_REGIONS) * SKR_PULL_STRIDE);
 	SKR_HIP(hipMemcpy(h.data(), r->d_counters + (size_t) SKR_COUNTER_SHARDS * 4 + 8, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
 	uint64_t total = 0;
@@ -425,47 +483,62 @@ int skr_renderer_last_level1_count(skr_renderer *r, uint32_t *n)
 	return SKR_OK;
 }
 
-int skr_renderer_read_counters(skr_renderer *r, uint64_t out[3], int reset)
+static int read_work(skr_renderer *r, uint64_t *out, int n_out, int reset)
 {
 	if(!r || !out) return SKR_ERR_ARG;
 	SKR_HIP(hipSetDevice(r->device));
-	std::vector<unsigned long long> h((size_t) SKR_COUNTER_SHARDS * 4 + 16);
+	// the work counters and (diagnostic builds) the 8 phase stamps behind them; the queue counters that follow are not touched
+	std::vector<unsigned long long> h((size_t) SKR_COUNTER_SHARDS * 4 + 8);
 	SKR_HIP(hipMemcpy(h.data(), r->d_counters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost)); // synchronises with prior launches
-	out[0] = out[1] = out[2] = 0;
+	for(int k = 0; k < n_out; k++) out[k] = 0;
 	for(size_t s = 0; s < SKR_COUNTER_SHARDS; s++)
-		for(int k = 0; k < 3; k++) out[k] += h[4 * s + k];
+		for(int k = 0; k < n_out; k++) out[k] += h[4 * s + k];
 	if(getenv("SKR_PRINT_STAMPS"))
 	{ // diagnostic builds (-DSKR_STAMPS=1) only: per-phase cycle sums
 		for(int k = 0; k < 8; k++) fprintf(stderr, "stamp[%d] = %llu\n", k, h[(size_t) SKR_COUNTER_SHARDS * 4 + k]);
 	}
+	// (null stream: callers read the counters between frames, after synchronising their render stream)
 	if(reset) SKR_HIP(hipMemset(r->d_counters, 0, h.size() * sizeof(unsigned long long)));
+	return SKR_OK;
+}
+
+int skr_renderer_read_counters(skr_renderer *r, uint64_t out[3], int reset) { return read_work(r, out, 3, reset); }
+
+int skr_renderer_read_work(skr_renderer *r, uint64_t out[4], int reset)
+{
+	const int rc = read_work(r, out, 4, reset);
+	if(rc != SKR_OK) return rc;
+	// every radiance ray tests every sphere (raytrace.h:152-165); a shadow ray stops at its first occluder (utils.h:52-55)
+	out[3] += out[0] * (uint64_t) r->info.n_spheres;
 	return SKR_OK;
 }
 
 int skr_render_frame_host(skr_renderer *r, const skr_options *opt, uint8_t *h_rgb, float *kernel_ms)
 {
 	if(!r || !opt || !h_rgb) return SKR_ERR_ARG;
+	int rc = check_options(opt); // before anything is sized from width x height
+	if(rc != SKR_OK) return rc;
 	SKR_HIP(hipSetDevice(r->device));
 	const size_t bytes = (size_t) opt->width * opt->height * 3;
-	uint8_t *d = nullptr;
-	SKR_HIP(hipMalloc((void **) &d, bytes));
-	hipEvent_t e0, e1;
-	SKR_HIP(hipEventCreate(&e0));
-	SKR_HIP(hipEventCreate(&e1));
-	SKR_HIP(hipEventRecord(e0, nullptr));
-	int rc = skr_render_tiles(r, opt, (uint32_t) opt->height, 0, 1, d, nullptr, nullptr);
-	if(rc == SKR_OK)
-	{
-		SKR_HIP(hipEventRecord(e1, nullptr));
-		SKR_HIP(hipMemcpy(h_rgb, d, bytes, hipMemcpyDeviceToHost));
-		float ms = 0;
-		SKR_HIP(hipEventElapsedTime(&ms, e0, e1));
-		if(kernel_ms) *kernel_ms = ms;
+	if(bytes > r->frame_cap)
+	{ // the device frame and the two events live in the renderer: nothing to leak on an early return
+		if(r->d_frame) SKR_HIP(hipFree(r->d_frame));
+		r->d_frame = nullptr;
+		r->frame_cap = 0;
+		SKR_HIP(hipMalloc((void **) &r->d_frame, bytes));
+		r->frame_cap = bytes;
 	}
-	(void) hipEventDestroy(e0);
-	(void) hipEventDestroy(e1);
-	(void) hipFree(d);
-	return rc;
+	if(!r->frame_e0) SKR_HIP(hipEventCreate(&r->frame_e0));
+	if(!r->frame_e1) SKR_HIP(hipEventCreate(&r->frame_e1));
+	SKR_HIP(hipEventRecord(r->frame_e0, nullptr));
+	rc = skr_render_tiles(r, opt, (uint32_t) opt->height, 0, 1, r->d_frame, nullptr, nullptr);
+	if(rc != SKR_OK) return rc;
+	SKR_HIP(hipEventRecord(r->frame_e1, nullptr));
+	SKR_HIP(hipMemcpy(h_rgb, r->d_frame, bytes, hipMemcpyDeviceToHost));
+	float ms = 0;
+	SKR_HIP(hipEventElapsedTime(&ms, r->frame_e0, r->frame_e1));
+	if(kernel_ms) *kernel_ms = ms;
+	return SKR_OK;
 }
 
 const char *skr_kernel_variant(void) { return g_variant; }

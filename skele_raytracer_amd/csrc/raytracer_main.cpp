@@ -21,7 +21,9 @@ int main(int argc, char *argv[])
 	const char *path = nullptr, *output = nullptr;
 	bool visual = true; // utils.h:29; kept for compatibility: there is no SDL viewer, both values render on the GPU
 	bool quiet = false;
-	int device = 0;
+	int device = 0, gpus = 1;
+	bool sharded = false; // --gpus given (even --gpus 1): the frame goes through the multi-GPU path
+	uint32_t tile_rows = 8;
 
 	for(int i = 0; i < argc; i++)
 	{
@@ -106,6 +108,8 @@ int main(int argc, char *argv[])
 		if(!strcmp(argv[i], "--shadow")) option.use_shadows = 1;
 		if(!strcmp(argv[i], "--seed") && has_next) option.seed = strtoull(argv[i + 1], nullptr, 10);
 		if(!strcmp(argv[i], "--device") && has_next) device = atoi(argv[i + 1]);
+		if(!strcmp(argv[i], "--gpus") && has_next) { gpus = atoi(argv[i + 1]) > 0 ? atoi(argv[i + 1]) : 1; sharded = true; }           // new: the frame sharded over the first N devices
+		if(!strcmp(argv[i], "--tile-rows") && has_next) tile_rows = (uint32_t) (atoi(argv[i + 1]) > 0 ? atoi(argv[i + 1]) : 8);
 		if(!strcmp(argv[i], "--quiet")) quiet = true;
 	}
 	if(!path)
@@ -129,23 +133,44 @@ int main(int argc, char *argv[])
 	printf("\n\nMonte carlo: %d\nvisual display: %d\nfov: %f\nnum paths traced: %d\nsupersample grid size: %d\nmax depth: %d\n",
 		   option.monte_carlo, visual ? 1 : 0, option.fov, option.num_path_traces, option.grid_size, option.max_depth);
 
-	skr_renderer *renderer = nullptr;
-	int rc = skr_renderer_create(scene, device, &renderer);
-	if(rc != SKR_OK)
-	{
-		std::cerr << "raytracer: " << skr_last_error() << std::endl;
-		return rc; // new failure class (the reference has no device): non-zero
+	if(option.width <= 0 || option.height <= 0 || option.width > 65536 || option.height > 65536)
+	{ // before anything is sized from it (the reference would allocate width x height vec3s here, main.cpp:125-128)
+		std::cerr << "raytracer: bad image size " << option.width << "x" << option.height << std::endl;
+		return SKR_ERR_ARG;
 	}
 	std::vector<uint8_t> rgb((size_t) option.width * option.height * 3);
 	float ms = 0;
-	rc = skr_render_frame_host(renderer, &option, rgb.data(), &ms);
-	if(rc != SKR_OK)
-	{
-		std::cerr << "raytracer: " << skr_last_error() << std::endl;
-		return rc;
-	}
 	uint64_t counters[3] = {0, 0, 0};
-	skr_renderer_read_counters(renderer, counters, 0);
+	int rc;
+	skr_renderer *renderer = nullptr;
+	skr_multi *multi = nullptr;
+	if(sharded)
+	{ // one process, N devices: interleaved row tiles, one RCCL all-gather, the root de-interleaves (include/skr.h "multi-GPU")
+		rc = skr_multi_create(scene, gpus, nullptr, &multi);
+		if(rc == SKR_OK) rc = skr_multi_render_frame_host(multi, &option, tile_rows, rgb.data(), &ms);
+		if(rc != SKR_OK)
+		{
+			std::cerr << "raytracer: " << skr_last_error() << std::endl;
+			return rc; // new failure class (the reference has no device): non-zero
+		}
+		for(int i = 0; i < gpus; i++)
+		{
+			uint64_t c[3] = {0, 0, 0};
+			skr_renderer_read_counters(skr_multi_renderer(multi, i), c, 0);
+			for(int k = 0; k < 3; k++) counters[k] += c[k];
+		}
+	}
+	else
+	{
+		rc = skr_renderer_create(scene, device, &renderer);
+		if(rc == SKR_OK) rc = skr_render_frame_host(renderer, &option, rgb.data(), &ms);
+		if(rc != SKR_OK)
+		{
+			std::cerr << "raytracer: " << skr_last_error() << std::endl;
+			return rc;
+		}
+		skr_renderer_read_counters(renderer, counters, 0);
+	}
 	rc = skr_write_ppm(output, (uint32_t) option.width, (uint32_t) option.height, rgb.data());
 	if(rc != SKR_OK)
 	{
@@ -153,8 +178,9 @@ int main(int argc, char *argv[])
 		return rc;
 	}
 	printf("***\nWROTE TO PPM\n***\n"); // main.cpp:213
-	fprintf(stderr, "{\"kernel\": \"%s\", \"frame_ms\": %.3f, \"radiance_rays\": %llu, \"mrays_per_s\": %.1f, \"shadow_rays\": %llu}\n",
-			skr_kernel_variant(), ms, (unsigned long long) counters[0], ms > 0 ? counters[0] / (ms * 1e3) : 0.0, (unsigned long long) counters[2]);
+	fprintf(stderr, "{\"gpus\": %d, \"kernel\": \"%s\", \"frame_ms\": %.3f, \"radiance_rays\": %llu, \"mrays_per_s\": %.1f, \"shadow_rays\": %llu}\n",
+			gpus > 1 ? gpus : 1, skr_kernel_variant(), ms, (unsigned long long) counters[0], ms > 0 ? counters[0] / (ms * 1e3) : 0.0, (unsigned long long) counters[2]);
+	skr_multi_destroy(multi);
 	skr_renderer_destroy(renderer);
 	skr_scene_destroy(scene);
 	return 0;

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void skr_render_kernel(const RenderParams p)
 
 	if(p.counters)
 	{
-		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays);
+		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays), d4 = wave_sum(cn.shadow_tests);
 		if(lane == 0)
 		{ // sharded: thousands of waves adding to ONE word serialise at ~88 atomics/us (1.1 ms per 1080p frame)
 			const uint32_t shard = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (uint32_t) wave) & (SKR_COUNTER_SHARDS - 1u);
@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256) void skr_render_kernel(const RenderParams p)
 			atomicAdd(&c4[0], (unsigned long long) a);
 			atomicAdd(&c4[1], (unsigned long long) b);
 			atomicAdd(&c4[2], (unsigned long long) c);
+			atomicAdd(&c4[3], (unsigned long long) d4);
 		}
 	}
 }
@@ -197,8 +198,7 @@ hipError_t skr_launch_nodes(const RenderParams &p, hipStream_t stream, const Skr
 // the per-pixel kernel covers the rest (depth 4..6).  SKR_KERNEL=v1 forces the latter (A/B runs).
 static bool use_wave_kernel(const RenderParams &p)
 {
-	const char *e = getenv("SKR_KERNEL");
-	if(e && !strcmp(e, "v1")) return false;
+	if(p.sw.kernel_v1) return false;
 	return skr_wave_supported(p);
 }
 

@@ -67,13 +67,14 @@ SKR_DEV SceneView stage_scene(const RenderParams &p, float4 *lds4, bool tris)
 SKR_DEV void add_counters(const RenderParams &p, const Counters &cn, uint32_t shard, int lane)
 {
 	if(!p.counters) return;
-	const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays);
+	const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays), d4 = wave_sum(cn.shadow_tests);
 	if(lane == 0)
 	{ // sharded: thousands of waves adding to one word serialise
 		unsigned long long *c4 = p.counters + 4u * (shard & (SKR_COUNTER_SHARDS - 1u));
 		if(a) atomicAdd(&c4[0], (unsigned long long) a);
 		if(b) atomicAdd(&c4[1], (unsigned long long) b);
 		if(c) atomicAdd(&c4[2], (unsigned long long) c);
+		if(d4) atomicAdd(&c4[3], (unsigned long long) d4);
 	}
 }
 
@@ -767,18 +768,16 @@ static bool plan_for(const RenderParams &p, uint32_t nblk, NodePlan &pl)
 	return true;
 }
 
-static uint64_t nodes_budget()
+static uint64_t nodes_budget(const RenderParams &p)
 {
-	uint64_t budget = 4ull << 30;
-	if(const char *e = getenv("SKR_LEVELS_BUDGET_MB")) budget = (uint64_t) (atoi(e) > 0 ? atoi(e) : 1) << 20; // tests: force several bands
-	return budget;
+	return p.sw.budget_mb ? (uint64_t) p.sw.budget_mb << 20 : 4ull << 30; // (tests force several bands with a small budget)
 }
 
 // the largest band (in 16x16 pixel blocks) whose worst-case tables fit the budget; false: not even one block does
 static bool skr_nodes_plan(const RenderParams &p, NodePlan &pl)
 {
 	const uint32_t bx = (uint32_t) (p.width + 15) / 16, by = (p.out_rows + 15) / 16;
-	const uint64_t budget = nodes_budget();
+	const uint64_t budget = nodes_budget(p);
 	uint32_t lo = 1, hi = bx * by;
 	if(!plan_for(p, lo, pl) || pl.banded > budget) return false;
 	if(plan_for(p, hi, pl) && pl.banded <= budget) return true;
@@ -803,9 +802,8 @@ bool skr_nodes_supported(const RenderParams &p)
 
 bool skr_nodes_selected(const RenderParams &p)
 {
-	const char *e = getenv("SKR_PIPELINE");
-	const bool forced = e && !strcmp(e, "nodes");
-	if(e && !forced) return false;
+	const bool forced = p.sw.pipeline == SKR_PIPE_NODES;
+	if(p.sw.pipeline != SKR_PIPE_AUTO && !forced) return false;
 	if(!skr_nodes_supported(p)) return false;
 	if(forced) return true;
 	// triangle meshes at depth 2..3 stay on the parent-queue pipeline (their rounds are long and few: DESIGN.md 5.0);
@@ -817,6 +815,17 @@ size_t skr_nodes_scratch_bytes(const RenderParams &p)
 {
 	NodePlan pl;
 	return skr_nodes_plan(p, pl) ? pl.total : 0;
+}
+
+// where the counters of the band last rendered sit in the scratch: [0] = level-0 nodes, then per level 64 region counts
+bool skr_nodes_counter_layout(const RenderParams &p, size_t *off_ctr, size_t *level_words, int *levels)
+{
+	NodePlan pl;
+	if(!skr_nodes_plan(p, pl)) return false;
+	*off_ctr = pl.off_ctr;
+	*level_words = LVL_CTR_WORDS;
+	*levels = pl.levels;
+	return true;
 }
 
 size_t skr_nodes_lds_bytes(const RenderParams &p) { return ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 32 + (size_t) 4 * LEAF2_WAVE_FLOATS * sizeof(float); }
@@ -852,10 +861,7 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 	p.ix_stride = pl.ix_stride;
 	p.stash = reinterpret_cast<float *>(base + pl.off_stash);
 	p.qctr = ctr0; // [0]: the primary kernel counts its level-0 nodes here
-	{
-		const char *e = getenv("SKR_UNIT_STRIDE");
-		p.unit_strided = e ? (atoi(e) != 0) : 0u;
-	}
+	p.unit_strided = (uint32_t) p.sw.unit_strided;
 	hipError_t e = hipSuccess;
 	for(int s = 0; s < nsamp; s++)
 	{

@@ -19,7 +19,21 @@ struct f3 {
 // level-queue pipeline: level-1 hits are appended to SKR_P1_REGIONS regions (one counter each, behind the pull counters)
 #define SKR_P1_REGIONS 64u
 
+// The SKR_* development switches (A/B runs, tests), read from the environment ONCE per renderer (skr_renderer_create,
+// skr_renderer_reload_switches) — the launch path never calls getenv.
+enum SkrPipeline { SKR_PIPE_AUTO = 0, SKR_PIPE_NODES, SKR_PIPE_LEVELS, SKR_PIPE_QUEUE, SKR_PIPE_MEGA, SKR_PIPE_OTHER };
+struct SkrSwitches {
+	int32_t pipeline = SKR_PIPE_AUTO; // SKR_PIPELINE = nodes | levels | queue | mega
+	int32_t kernel_v1 = 0;            // SKR_KERNEL = v1: the lane-per-pixel kernel
+	int32_t occ = 0;                  // SKR_OCC = 2 | 3: LDS/VGPR budget of the streaming kernels (0 = choose)
+	int32_t tile = 0;                 // SKR_TILE = 64 | 32 | 16: pixels per wave tile of the megakernel (0 = choose)
+	int32_t no_cones = 0, no_cull = 0; // SKR_NO_CONES, SKR_NO_CULL: triangle-walk culling off
+	int32_t budget_mb = 0;            // SKR_LEVELS_BUDGET_MB: scratch budget of the level pipelines (0 = default)
+	int32_t unit_strided = 0;         // SKR_UNIT_STRIDE
+};
+
 struct RenderParams {
+	SkrSwitches sw; // (host side only)
 	// image and partition (include/skr.h skr_render_tiles)
 	int32_t width, height;
 	uint32_t tile_rows, first_tile, tile_stride, out_rows;

@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 #endif
 	if(p.counters)
 	{
-		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays);
+		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays), d4 = wave_sum(cn.shadow_tests);
 		if(lane == 0)
 		{ // sharded: thousands of waves adding to ONE word serialise at ~88 atomics/us (1.1 ms per 1080p frame)
 			const uint32_t shard = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (uint32_t) wave) & (SKR_COUNTER_SHARDS - 1u);
@@ -777,6 +777,7 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 			atomicAdd(&c4[0], (unsigned long long) a);
 			atomicAdd(&c4[1], (unsigned long long) b);
 			atomicAdd(&c4[2], (unsigned long long) c);
+			atomicAdd(&c4[3], (unsigned long long) d4);
 		}
 	}
 }
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(256) void skr_primary_kernel(const RenderParams p)
 	else if(valid) emit_sample(p, out_pix, colour); // this sample of this pixel is final
 	if(p.counters)
 	{
-		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays);
+		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays), d4 = wave_sum(cn.shadow_tests);
 		if(lane == 0)
 		{
 			const uint32_t shard = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (uint32_t) wave) & (SKR_COUNTER_SHARDS - 1u);
@@ -905,6 +906,7 @@ __global__ __launch_bounds__(256) void skr_primary_kernel(const RenderParams p)
 			atomicAdd(&c4[0], (unsigned long long) a);
 			atomicAdd(&c4[1], (unsigned long long) b);
 			atomicAdd(&c4[2], (unsigned long long) c);
+			atomicAdd(&c4[3], (unsigned long long) d4);
 		}
 	}
 }
@@ -1056,7 +1058,7 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 #endif
 	if(p.counters)
 	{
-		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays);
+		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays), d4 = wave_sum(cn.shadow_tests);
 		if(lane == 0)
 		{
 			const uint32_t shard = (blockIdx.x * 4u + (uint32_t) wave) & (SKR_COUNTER_SHARDS - 1u);
@@ -1064,6 +1066,7 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 			atomicAdd(&c4[0], (unsigned long long) a);
 			atomicAdd(&c4[1], (unsigned long long) b);
 			atomicAdd(&c4[2], (unsigned long long) c);
+			atomicAdd(&c4[3], (unsigned long long) d4);
 		}
 	}
 }
@@ -1372,13 +1375,14 @@ __global__ __launch_bounds__(256, 4) void skr_leaf_kernel(const RenderParams p)
 #endif
 	if(p.counters)
 	{
-		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays);
+		const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays), d4 = wave_sum(cn.shadow_tests);
 		if(lane == 0)
 		{
 			unsigned long long *c4 = p.counters + 4u * (g & (SKR_COUNTER_SHARDS - 1u));
 			atomicAdd(&c4[0], (unsigned long long) a);
 			atomicAdd(&c4[1], (unsigned long long) b);
 			atomicAdd(&c4[2], (unsigned long long) c);
+			atomicAdd(&c4[3], (unsigned long long) d4);
 		}
 	}
 }
@@ -1471,8 +1475,7 @@ static size_t wave_block_lds(const RenderParams &p, int occ, bool global0 = fals
 // waves per SIMD is the worst of both).  SKR_OCC=2|3 forces one (A/B runs).
 static int wave_occ_for(const RenderParams &p)
 {
-	const char *e = getenv("SKR_OCC");
-	if(e) return atoi(e) >= 3 ? 3 : 2;
+	if(p.sw.occ) return p.sw.occ;
 	// (and for gillum < 8 the small budget's 8-parent groups cannot fill a 64-lane round)
 	if(p.monte_carlo && p.n_spheres > 0 && p.max_depth > 1 && (p.num_path_traces > 32 || p.num_path_traces < 8)) return 2;
 	// measured on MI355X: LDS is granted in 1280-byte granules (160 KiB / 128): 3 x 53,264 B and
@@ -1518,8 +1521,7 @@ hipError_t skr_launch_wave(const RenderParams &p_in, hipStream_t stream)
 		const uint64_t pixels = (uint64_t) p.width * p.out_rows;
 		if(pixels / 32 < 8 * slots) tile_px = 16;
 		if(!p.monte_carlo || p.n_spheres == 0 || p.max_depth < 2) tile_px = 64;
-		const char *e = getenv("SKR_TILE");
-		if(e && (atoi(e) == 64 || atoi(e) == 32 || atoi(e) == 16)) tile_px = atoi(e);
+		if(p.sw.tile) tile_px = p.sw.tile;
 	}
 	p.tile_w_log2 = tile_px == 16 ? 2 : 3;
 	p.tile_h_log2 = tile_px == 64 ? 3 : 2;
@@ -1548,9 +1550,8 @@ hipError_t skr_launch_wave(const RenderParams &p_in, hipStream_t stream)
 // Used for --gillum trees (depth 2..3) unless SKR_PIPELINE=mega asks for the single megakernel.
 bool skr_queue_selected(const RenderParams &p)
 {
-	const char *e = getenv("SKR_PIPELINE");
-	if(e && !strcmp(e, "mega")) return false;
-	if(e && !strcmp(e, "queue")) return skr_wave_supported(p) && p.monte_carlo && p.max_depth >= 2 && p.num_path_traces > 0;
+	if(p.sw.pipeline == SKR_PIPE_MEGA) return false;
+	if(p.sw.pipeline == SKR_PIPE_QUEUE) return skr_wave_supported(p) && p.monte_carlo && p.max_depth >= 2 && p.num_path_traces > 0;
 	return skr_wave_supported(p) && p.monte_carlo && p.n_spheres > 0 && p.max_depth >= 2 && p.num_path_traces > 0;
 }
 
@@ -1568,7 +1569,7 @@ static uint32_t levels_band_rows(const RenderParams &p)
 { // rows per band: the level-1 records of a band (64 B x 2 x width x N / 2 per row, every pixel a parent, every child a hit)
   // stay within ~3 GiB; a 1080p --gillum 16 frame is one band, 4K --gillum 64 works in bands of ~200 rows
 	uint64_t budget = 3ull << 30;
-	if(const char *e = getenv("SKR_LEVELS_BUDGET_MB")) budget = (uint64_t) (atoi(e) > 0 ? atoi(e) : 1) << 20; // tests: force several bands
+	if(p.sw.budget_mb) budget = (uint64_t) p.sw.budget_mb << 20; // tests: force several bands
 	const uint64_t per_row = (uint64_t) p.width * (uint64_t) (((p.num_path_traces + 1) >> 1) * 2) * 64;
 	uint64_t rows = budget / (per_row ? per_row : 1);
 	rows = rows / 16 * 16;
@@ -1591,9 +1592,8 @@ static uint64_t levels_tasks_max(const RenderParams &p, uint32_t rows)
 // their rounds are long and few).  SKR_PIPELINE=levels | queue | mega forces one.
 bool skr_levels_selected(const RenderParams &p)
 {
-	const char *e = getenv("SKR_PIPELINE");
-	const bool forced = e && !strcmp(e, "levels");
-	if(e && !forced) return false;
+	const bool forced = p.sw.pipeline == SKR_PIPE_LEVELS;
+	if(!forced) return false; // round 1's pipeline: A/B runs only (the node pipeline of render_nodes.hip replaced it)
 	if(!(skr_wave_supported(p) && p.monte_carlo && p.n_spheres > 0 && p.max_depth == 3 && p.num_path_traces > 0 && p.num_path_traces <= 255)) return false;
 	if(p.n_tris > 64 && !forced) return false; // a handful of triangles costs nothing (spheres1: 1.31 -> 1.18 ms); meshes stay on the parent queue
 	return levels_tasks_max(p, levels_band_rows(p)) * 3 < (1ull << 30);

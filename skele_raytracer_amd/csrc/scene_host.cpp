@@ -495,8 +495,14 @@ int skr_parse_scn(const std::string &path, bool echo, skr_scene &sc)
 		{
 			float v[3] = {0, 0, 0}; // scene.cpp:69-70: indices are read as floats
 			read_floats(args, v, 3);
-			long idx[3] = {(long) v[0], (long) v[1], (long) v[2]};
+			// the float is range-checked BEFORE the conversion: (long) of nan, inf or 1e39 is undefined behaviour
+			long idx[3] = {0, 0, 0};
 			bool ok = true;
+			for(int k = 0; k < 3; k++)
+			{
+				ok = ok && std::isfinite(v[k]) && v[k] > -1.0f && v[k] < (float) info.n_vertices; // (long) truncates: -0.5 -> 0
+				if(ok) idx[k] = (long) v[k];
+			}
 			for(long i : idx) ok = ok && i >= 0 && i < info.n_vertices;
 			if(!ok)
 			{ // the reference reads out of bounds here; no shipped scene does
@@ -573,7 +579,7 @@ int skr_parse_scn(const std::string &path, bool echo, skr_scene &sc)
 			float n = 0;
 			read_floats(args, &n, 1);
 			if(echo) printf("max_depth %f\n", n);
-			info.max_depth_parsed = (int) n;
+			info.max_depth_parsed = (std::isfinite(n) && n > -2147483648.0f && n < 2147483648.0f) ? (int) n : 0; // (int) of nan / 1e30 is undefined
 		}
 		else if(cmd == "output_image")
 		{

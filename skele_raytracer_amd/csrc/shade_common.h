@@ -28,6 +28,7 @@ struct SceneView {
 
 struct Counters {
 	uint32_t rays, hits, shadow_rays;
+	uint32_t shadow_tests; // ray-sphere tests of utils.h:42-58 as the reference runs them: up to and including the first occluder
 };
 
 struct RayConst { // per-ray invariants of utils.h:113-121
@@ -200,7 +201,7 @@ SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float t
 
 // utils.h:42-58: any sphere with 1 < t < inf along the (unbounded) shadow ray; two lights at a
 // time, because both shadow rays start at the same point and share e and c per sphere.
-SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second, bool &occ0, bool &occ1)
+SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second, bool &occ0, bool &occ1, uint32_t &tests)
 {
 	const f3 o = add_scalar(P, 0.000001f);
 	const RayPair rp = make_pair(L0, L1);
@@ -228,8 +229,16 @@ SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second,
 			DIAG_LANES(6);
 			f2 m, al, rl;
 			pair_any_m(pa, b, m, al, rl);
-			if(cand0) occ0 = any_decide(pa.sane0, pa.two_a.x, pa.quarter.x, b.x, D.x, m.x, al.x, rl.x);
-			if(cand1) occ1 = any_decide(pa.sane1, pa.two_a.y, pa.quarter.y, b.y, D.y, m.y, al.y, rl.y);
+			if(cand0)
+			{
+				occ0 = any_decide(pa.sane0, pa.two_a.x, pa.quarter.x, b.x, D.x, m.x, al.x, rl.x);
+				if(occ0) tests += (uint32_t) i + 1u; // the reference's loop returns here (utils.h:52-55)
+			}
+			if(cand1)
+			{
+				occ1 = any_decide(pa.sane1, pa.two_a.y, pa.quarter.y, b.y, D.y, m.y, al.y, rl.y);
+				if(occ1) tests += (uint32_t) i + 1u;
+			}
 #if defined(SKR_DIAG) && SKR_DIAG
 			{
 				const unsigned long long c0 = __ballot(cand0), c1 = __ballot(cand1), o0 = __ballot(cand0 && occ0), o1 = __ballot(cand1 && occ1);
@@ -240,6 +249,8 @@ SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second,
 		}
 		if(__all(occ0 && occ1)) break;
 	}
+	if(!occ0) tests += (uint32_t) sv.ns;
+	if(second && !occ1) tests += (uint32_t) sv.ns;
 	if(!second) occ1 = false;
 }
 
@@ -275,7 +286,7 @@ SKR_DEV f3 direct_light(const SceneView &sv, const RenderParams &p, int sph, f3 
 		if(p.use_shadows)
 		{
 			cn.shadow_rays += second ? 2u : 1u;
-			occluded_pair(sv, P, t0.L, t1.L, second, occ0, occ1);
+			occluded_pair(sv, P, t0.L, t1.L, second, occ0, occ1, cn.shadow_tests);
 		}
 #pragma nounroll
 		for(int k = 0; k < 2; k++)

@@ -18,17 +18,32 @@ import sys
 import time
 
 
+def _atoi(s):
+    """C atoi: leading white space, an optional sign, digits; 0 when there are none (what main.cpp:246-379 calls)."""
+    import re
+    m = re.match(r"[ \t\n\v\f\r]*([+-]?\d+)", s)
+    return max(-2 ** 31, min(2 ** 31 - 1, int(m.group(1)))) if m else 0
+
+
+def _atof(s):
+    """C atof: the longest leading decimal / hex-float / inf / nan prefix; 0.0 when there is none."""
+    import re
+    m = re.match(r"[ \t\n\v\f\r]*([+-]?(?:0[xX](?:[0-9a-fA-F]+\.?[0-9a-fA-F]*|\.[0-9a-fA-F]+)(?:[pP][+-]?\d+)?|(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?|inf(?:inity)?|nan))", s, re.I)
+    if not m:
+        return 0.0
+    t = m.group(1)
+    return float.fromhex(t) if "x" in t.lower() else float(t)
+
+
 def _parse(argv):
-    """main.cpp:246-379: flags anywhere, the value is the next token; bad numbers are usage errors."""
+    """main.cpp:246-379 as bin/raytracer restates it: flags anywhere, the value is the next token read with atoi / atof
+    (`--width abc` is width 0, not a usage error); only a MISSING value is a usage error — and for --gillum a warning."""
     opt = dict(path=None, output=None, width=1920, height=1080, fov=60.0, gillum=None, jsample=None, depth=3, shadow=False, seed=1, tile_rows=8)
 
     def value(i, kind, what):
         if i + 1 >= len(argv):
             raise ValueError(what)
-        try:
-            return kind(argv[i + 1])
-        except ValueError:
-            raise ValueError(what)
+        return kind(argv[i + 1])
 
     for i, a in enumerate(argv):
         if a == "--path":
@@ -36,30 +51,28 @@ def _parse(argv):
         elif a == "--output":
             opt["output"] = value(i, str, "output path must be passed after --output")
         elif a == "--width":
-            opt["width"] = value(i, int, "width takes an int after flag for the width")
+            opt["width"] = value(i, _atoi, "width takes an int after flag for the width")
         elif a == "--height":
-            opt["height"] = value(i, int, "height takes an int after flag for the width")
+            opt["height"] = value(i, _atoi, "height takes an int after flag for the width")
         elif a == "--fov":
-            opt["fov"] = value(i, float, "fov takes a float (degrees) after flag for the field of view")
+            opt["fov"] = value(i, _atof, "fov takes a float (degrees) after flag for the field of view")
         elif a == "--gillum":
-            try:
-                opt["gillum"] = value(i, int, "")
-            except ValueError:  # main.cpp:258 warns and goes on
+            if i + 1 < len(argv):  # main.cpp:250-253: monte_carlo = true, num_path_traces = atoi(next) — 0 for a non-number
+                opt["gillum"] = _atoi(argv[i + 1])
+            else:  # main.cpp:258 warns and goes on
                 print("gillum takes an int after flag for the number of paths traced", file=sys.stderr)
         elif a == "--jsample":
-            opt["jsample"] = value(i, int, "jsample takes an int after flag for the supersampling grid size")
+            opt["jsample"] = value(i, _atoi, "jsample takes an int after flag for the supersampling grid size")
         elif a == "--depth":
-            opt["depth"] = value(i, int, "depth takes a positive int after flag for the max depth")
+            opt["depth"] = value(i, _atoi, "depth takes a positive int after flag for the max depth")
+            if opt["depth"] <= 0:
+                raise ValueError("depth takes a positive int after flag for the max depth")
         elif a == "--shadow":
             opt["shadow"] = True
         elif a == "--seed":
-            opt["seed"] = value(i, int, "seed takes an int")
+            opt["seed"] = value(i, _atoi, "seed takes an int")
         elif a == "--tile-rows":
-            opt["tile_rows"] = value(i, int, "tile-rows takes a positive int")
-    if opt["width"] <= 0 or opt["height"] <= 0:
-        raise ValueError("width/height take a positive int")
-    if opt["depth"] <= 0:
-        raise ValueError("depth takes a positive int after flag for the max depth")
+            opt["tile_rows"] = value(i, _atoi, "tile-rows takes a positive int")
     if opt["tile_rows"] <= 0:
         raise ValueError("tile-rows takes a positive int")
     if opt["path"] is None:
@@ -76,6 +89,9 @@ def main(argv=None):
     except ValueError as e:
         print(str(e), file=sys.stderr)
         return 0  # the reference's usage errors leave with status 0
+    if o["width"] <= 0 or o["height"] <= 0 or o["width"] > 65536 or o["height"] > 65536:
+        print("raytracer: bad image size %dx%d" % (o["width"], o["height"]), file=sys.stderr)  # as bin/raytracer: before anything is sized from it
+        return 2
     import torch
     import torch.distributed as dist
     import skele_raytracer_amd as skr

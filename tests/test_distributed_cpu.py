@@ -69,3 +69,17 @@ def test_partition_arithmetic():
         f = D.deinterleave(g, h, tile, world)
         assert f.shape[0] == h
         assert all(int(f[y, 0, 0]) == (y // tile) % 251 for y in range(h))
+
+
+def test_native_partition_matches_the_python_one():
+    """libskr's own partition helpers (include/skr.h skr_shard_*: what skr_comm_render_frame / skr_multi_render_frame
+    and their de-interleave kernel implement) against distributed.py on the same buffers — host logic, no GPU."""
+    from skele_raytracer_amd import binding
+    rng = np.random.default_rng(5)
+    for h, tile, world, w in [(1080, 8, 8, 16), (53, 8, 3, 7), (7, 16, 4, 5), (2160, 16, 8, 4), (100, 5, 1, 3), (33, 8, 6, 9)]:
+        k_max = binding.shard_tiles_per_rank(h, tile, world)
+        assert k_max == D.tiles_per_rank(h, tile, world)
+        g = rng.integers(0, 256, (world, k_max * tile, w, 3), dtype=np.uint8)
+        want = D.deinterleave(torch.from_numpy(g), h, tile, world).numpy()
+        got = binding.shard_deinterleave_host(g, w, h, tile, world)
+        assert np.array_equal(got, want)

@@ -613,6 +613,61 @@ def test_multi_rank_paths_rehearsed_on_one_gpu(gpu, tmp_path, world):
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == world and out["steps"] == 3 and out["scaling"] == "strong" and "REHEARSAL" in out["config"]["gather"]
+    assert out["n_gpus"] == world and out["steps"] == 3 and out["scaling"] == "strong" and "REHEARSAL" in out["config"]["frame_step"]
     assert out["config"]["rays_per_frame"] == 72909584.0 and out["config"]["shadow_rays_per_frame"] == 34474374.0
     assert "cpu_baseline" not in out and out["roofline"]["kernel_ms"] > 0
+
+
+def test_native_frame_step_on_one_gpu(gpu, tmp_path):
+    """The multi-GPU frame step that lives inside libskr (include/skr.h "multi-GPU": tiles into the gather buffer, ONE
+    ncclAllGather, de-interleave kernel), as far as a one-GPU box can run it: a world of one with a real RCCL communicator
+    (skr_comm_*: what bench.py uses under torchrun), the single-process form on one device (skr_multi_*: what
+    `raytracer --gpus N` uses) and the CLI flag itself — each must produce the frame of a plain skr_render_tiles call."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    w, h = 333, 187
+    opt = skr.Options(w, h, gillum=4, jsample=2, shadow=True, seed=5)
+    r = renderer("spheres2.scn")
+    want, _ = r.render(opt)
+    want = want.cpu().numpy()
+    assert binding.rccl_available()
+    for with_rccl in (False, True):  # without RCCL at all; with a communicator of one rank
+        for tile_rows in (8, 16, 5):
+            c = binding.Comm(r, 0, 1, binding.comm_unique_id() if with_rccl else None)
+            st = gpu.cuda.current_stream().cuda_stream
+            assert c.render_frame(opt, tile_rows, st)
+            got = c.frame_to_host(opt, st)
+            assert np.array_equal(got, want), (with_rccl, tile_rows)
+            c.close()
+    m = binding.Multi(renderer("spheres2.scn").scene, 1)
+    got, ms = m.render_frame_host(opt, 8)
+    assert np.array_equal(got, want) and ms > 0
+    assert m.counters()["radiance_rays"] > 0
+    m.close()
+    exe = os.path.join(ROOT, "bin", "raytracer")
+    args = ["--path", scene_path("spheres2.scn"), "--width", str(w), "--height", str(h), "--gillum", "4", "--jsample", "2", "--shadow", "--seed", "5", "--quiet"]
+    a, b = str(tmp_path / "one.ppm"), str(tmp_path / "sharded.ppm")
+    subprocess.run([exe] + args + ["--output", a], check=True, capture_output=True, timeout=120)
+    res = subprocess.run([exe] + args + ["--output", b, "--gpus", "1", "--tile-rows", "16"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and '"gpus": 1' in res.stderr, res.stderr
+    assert open(a, "rb").read() == open(b, "rb").read()
+    res = subprocess.run([exe] + args + ["--output", b, "--gpus", "2"], capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "visible" in res.stderr  # one GPU on this box: a loud failure, not a silent fallback
+
+
+def test_sphere_tests_are_counted_like_the_reference_runs_them(gpu, oracle):
+    """bench.py's FP32-VALU roofline is priced on the ray-sphere tests the reference's loops execute — every sphere for a
+    radiance ray (raytrace.h:152-165), up to and including the first occluder for a shadow ray (utils.h:52-55).  The
+    kernels count them (skr_renderer_read_work); the oracle counts them in its own loops."""
+    for scn, w, h, kw, env in (("spheres2.scn", 240, 135, dict(gillum=16, shadow=True, seed=20261004), {}),
+                               ("spheres2.scn", 160, 90, dict(jsample=3, shadow=True, seed=2), {}),
+                               ("bear.scn", 96, 72, dict(gillum=8, shadow=True, depth=4, seed=9), {}),
+                               ("spheres1.scn", 200, 113, dict(gillum=5, shadow=True, depth=2, seed=1), {})):
+        r = renderer(scn)
+        r.work(reset=True)
+        r.render(skr.Options(w, h, **kw))
+        gpu.cuda.synchronize()
+        got = r.work()
+        _, _, st = oracle.render(scene_path(scn), w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, **kw)
+        assert (got["radiance_rays"], got["sphere_hits"], got["shadow_rays"], got["sphere_tests"]) == tuple(int(v) for v in st[:4]), (scn, kw, r.kernel_variant())

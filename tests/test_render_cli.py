@@ -20,7 +20,7 @@ def test_defaults_are_the_reference_defaults():
     (["--output", "b.ppm"], "no scene file was passed"),
     (["--path", "a.scn"], "no output destination was passed"),
     (["--path", "a.scn", "--output", "b.ppm", "--depth", "0"], "depth takes a positive int"),
-    (["--path", "a.scn", "--output", "b.ppm", "--width", "x"], "width takes an int"),
+    (["--path", "a.scn", "--output", "b.ppm", "--width"], "width takes an int"),
     (["--path", "a.scn", "--output", "b.ppm", "--fov"], "fov takes a float"),
     (["--path"], "path must be passed after --path"),
 ])
@@ -29,6 +29,20 @@ def test_usage_errors_exit_zero_with_the_reference_message(capsys, argv, msg):
     assert msg in capsys.readouterr().err
 
 
-def test_gillum_without_a_number_only_warns(capsys):
-    o = render_cli._parse(["--path", "a.scn", "--output", "b.ppm", "--gillum", "many"])
+def test_gillum_without_a_value_only_warns(capsys):
+    o = render_cli._parse(["--path", "a.scn", "--output", "b.ppm", "--gillum"])
     assert o["gillum"] is None and "gillum takes an int" in capsys.readouterr().err
+
+
+def test_numbers_are_read_like_atoi_and_atof():
+    """The reference (and bin/raytracer) read values with atoi/atof: a non-number is 0, trailing junk is dropped, and a
+    --gillum with a non-number still switches Monte Carlo on with N = 0 (main.cpp:250-253)."""
+    o = render_cli._parse(["--path", "a.scn", "--output", "b.ppm", "--width", "abc", "--height", "36px", "--gillum", "many", "--jsample", " 3x", "--fov", "45.5deg"])
+    assert (o["width"], o["height"], o["gillum"], o["jsample"], o["fov"]) == (0, 36, 0, 3, 45.5)
+    assert render_cli._atoi("-12abc") == -12 and render_cli._atoi("") == 0 and render_cli._atoi("+7") == 7
+    assert render_cli._atof("1e2x") == 100.0 and render_cli._atof(".5") == 0.5 and render_cli._atof("x") == 0.0 and render_cli._atof("0x10") == 16.0
+
+
+def test_bad_image_size_is_refused_before_anything_is_sized(capsys):
+    assert render_cli.main(["--path", "a.scn", "--output", "b.ppm", "--width", "abc"]) == 2
+    assert "bad image size" in capsys.readouterr().err

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build
-g++ -std=c++17 -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -Iinclude -o build/sanitize_host tools/sanitize_host.cpp skele_raytracer_amd/csrc/scene_host.cpp
+g++ -std=c++17 -g -O1 -fsanitize=address,undefined,float-cast-overflow -fno-omit-frame-pointer -Iinclude -o build/sanitize_host tools/sanitize_host.cpp skele_raytracer_amd/csrc/scene_host.cpp
 printf 'sphere 1 2\nvertex 1 2\ntriangle 0 1 999999\ntriangle -5 0 1\nmaterial 1\ncamera\npoint_light 1 2 3\nvertex nan inf -inf\nvertex 1e39 0 0\ntriangle 0 0 0\ntriangle 1.7 0.2 2.9\n' > build/bad1.scn
 : > build/empty.scn
 python3 - <<'PY'
