@@ -58,7 +58,7 @@ typedef struct {
 
 typedef struct {
 	int32_t n_spheres, n_triangles, n_point_lights, n_vertices;
-	int32_t n_directional_dropped; /* parsed and never pushed, scene.cpp:139-163 */
+	int32_t n_directional_dropped; /* parsed and never pushed, scene.cpp:139-163 (0 under SKR_SCN_STRICT) */
 	int32_t n_fog_skipped;         /* spherical_fog lines (UB in the reference, scene.cpp:207-212): warned + skipped */
 	int32_t n_unknown;             /* "WARNING. Do not know command" lines, scene.cpp:214-217 */
 	int32_t n_bad_triangles;       /* triangle lines whose indices fall outside the vertex pool (skipped) */
@@ -67,11 +67,18 @@ typedef struct {
 	float camera[13];              /* position, direction, up, right (camera.h:30), half_height_angle */
 	float background[3];
 	float ambient[3];
+	int32_t n_directional_lights;  /* SKR_SCN_STRICT: directional lights kept (after the point lights in shading order) */
 } skr_scene_info;
 
 /* ---- scene: replaces Scene parseScene(std::string) (scene.cpp:12-227) ---- */
 /* echo != 0 prints the reference's per-line echo to stdout (scene.cpp:50,...). */
 int skr_scene_create_from_scn(const char *path, int echo, skr_scene **out);
+/* flags: SKR_SCN_STRICT = the loader as its author evidently meant it (`raytracer --strict-scn`):
+ * directional lights are pushed (scene.cpp:139-163 builds each one, clamps its colour to <= 1 and forgets the push_back)
+ * and shaded by the reference's own loops (blinn_phong.h:77-85,122-131; shadow test utils.h:60-76).  film_resolution and
+ * max_depth are reported in skr_scene_info either way; --strict-scn makes the CLI honour them. */
+#define SKR_SCN_STRICT 1u
+int skr_scene_create_from_scn_ex(const char *path, int echo, uint32_t flags, skr_scene **out);
 /* Build a scene from arrays (synthetic tests): spheres[n][14] = centre(3) radius
  * ambient(3) diffuse(3) specular(3) power; triangles[n][9] = v0 v1 v2;
  * point_lights[n][6] = position colour; camera[9] = position direction up. */

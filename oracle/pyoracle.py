@@ -34,6 +34,10 @@ class PointLight(C.Structure):
     _fields_ = [("position", Vec3), ("colour", Vec3)]
 
 
+class DirectionalLight(C.Structure):
+    _fields_ = [("direction", Vec3), ("colour", Vec3)]
+
+
 class Scene(C.Structure):
     _fields_ = [("cam_pos", Vec3), ("cam_dir", Vec3), ("cam_up", Vec3), ("cam_right", Vec3),
                 ("cam_half_angle", C.c_float), ("background", Vec3), ("ambient", Vec3),
@@ -43,7 +47,8 @@ class Scene(C.Structure):
                 ("point_lights", C.POINTER(PointLight)),
                 ("film_w", C.c_int), ("film_h", C.c_int), ("max_depth_parsed", C.c_int),
                 ("n_directional_dropped", C.c_int), ("n_fog_skipped", C.c_int),
-                ("n_unknown", C.c_int), ("n_bad_triangles", C.c_int)]
+                ("n_unknown", C.c_int), ("n_bad_triangles", C.c_int),
+                ("n_directional_lights", C.c_int), ("directional_lights", C.POINTER(DirectionalLight))]
 
 
 class Options(C.Structure):
@@ -69,6 +74,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.sko_scene_load.argtypes = [C.c_char_p, C.POINTER(Scene)]
         L.sko_scene_load.restype = C.c_int
+        L.sko_scene_load_ex.argtypes = [C.c_char_p, C.c_int, C.POINTER(Scene)]
+        L.sko_scene_load_ex.restype = C.c_int
         L.sko_scene_free.argtypes = [C.POINTER(Scene)]
         L.sko_render.argtypes = [C.POINTER(Scene), C.POINTER(Options), C.c_void_p, C.c_void_p, C.c_void_p]
         L.sko_render.restype = C.c_int
@@ -91,9 +98,10 @@ def lib():
 
 
 class OracleScene:
-    def __init__(self, path):
+    def __init__(self, path, strict=False):
+        """strict: the --strict-scn loader (directional lights kept: skr_oracle.h sko_scene_load_ex)."""
         self.s = Scene()
-        if lib().sko_scene_load(os.fsencode(path), C.byref(self.s)) != 0:
+        if lib().sko_scene_load_ex(os.fsencode(path), int(bool(strict)), C.byref(self.s)) != 0:
             raise FileNotFoundError(path)
 
     def __del__(self):
@@ -116,10 +124,10 @@ def host_cores():
 
 
 def render(scene, width, height, *, fov=60.0, gillum=None, jsample=0, depth=3, shadow=False,
-           rng=RNG_COUNTER, math=MATH_SHARED, seed=1, y0=0, y1=None, threads=None, want_float=False):
+           rng=RNG_COUNTER, math=MATH_SHARED, seed=1, y0=0, y1=None, threads=None, want_float=False, strict=False):
     """Returns (rgb uint8 [rows,W,3], float image or None, stats uint64[5])."""
     if isinstance(scene, (str, os.PathLike)):
-        scene = OracleScene(scene)
+        scene = OracleScene(scene, strict=strict)
     y1 = height if y1 is None else y1
     o = Options(width, height, fov, 0 if gillum is None else 1, 1 if gillum is None else gillum, jsample,
                 depth, int(bool(shadow)), rng, math, seed, y0, y1, threads or host_cores())

@@ -123,7 +123,7 @@ int main(int argc, char **argv)
 	Options option;
 	const char *path = nullptr, *output = nullptr, *float_out = nullptr, *dump = nullptr;
 	int width = 1920, height = 1080; // scene.h:15 defaults, overridden by CLI (main.cpp:393-395)
-	bool use_shadows = false, parallel_entry = false;
+	bool use_shadows = false, parallel_entry = false, strict = false;
 	unsigned seed = 1;
 
 	for(int i = 1; i < argc; i++)
@@ -146,6 +146,7 @@ int main(int argc, char **argv)
 		else if(!strcmp(argv[i], "--float-out")) float_out = next();
 		else if(!strcmp(argv[i], "--dump-scene")) dump = next();
 		else if(!strcmp(argv[i], "--parallel-entry")) parallel_entry = true;
+		else if(!strcmp(argv[i], "--strict")) strict = true;
 	}
 	if(!path || (!output && !dump))
 	{
@@ -180,6 +181,29 @@ int main(int argc, char **argv)
 	close(saved);
 
 	scene.spherical_fog.clear(); // pinned: UB fog line ignored (see header)
+	if(strict)
+	{ // --strict-scn: scene.cpp:139-163 builds every directional light and forgets to push it.  The lines are
+	  // read again here exactly as scene.cpp reads them (same sscanf, same clamp) and pushed; everything that SHADES them —
+	  // blinn_phong.h:77-85,122-131, utils.h:60-76 — is the reference's own, unmodified code.
+		FILE *fp = fopen(resolved, "r");
+		char line[1024], command[100];
+		while(fp && fgets(line, 1024, fp))
+		{
+			if(line[0] == '#') continue;
+			if(sscanf(line, "%s ", command) < 1) continue;
+			if(strcmp(command, "directional_light") != 0) continue;
+			float r, g, b, x, y, z;
+			sscanf(line, "directional_light %f %f %f %f %f %f", &r, &g, &b, &x, &y, &z);
+			if(r > 1) r = 1;
+			if(g > 1) g = 1;
+			if(b > 1) b = 1;
+			DirectionalLight directional_light;
+			directional_light.direction = glm::vec3(x, y, z);
+			directional_light.colour	= glm::vec3(r, g, b);
+			scene.directional_lights.push_back(directional_light);
+		}
+		if(fp) fclose(fp);
+	}
 	scene.width		  = width;
 	scene.height	  = height;
 	scene.use_shadows = use_shadows;

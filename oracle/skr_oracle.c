@@ -361,6 +361,18 @@ static v3 direct_illumination(ctx_t *cx, const sko_sphere *sp, v3 P, v3 N)
 		v3 H = vdivs(vl, vlength(vl));
 		specular = vadd(specular, vscale(vscale(vmul(sp->specular, pl->colour), intensity), powf_mode(cx, max0(vdot(N, H)), sp->power)));
 	}
+	/* blinn_phong.h:77-85 and :122-131 (empty at HEAD: scene.cpp never pushes a directional light; --strict-scn does).
+	 * shadow(Scene, P, DirectionalLight), utils.h:60-76, is the point-light test along normalize(direction). */
+	for(int i = 0; i < sc->n_directional_lights; i++)
+	{
+		const sko_directional_light *dl = &sc->directional_lights[i];
+		v3 L = vnormalize(dl->direction);
+		if(cx->op->use_shadows && shadowed(cx, P, L)) continue;
+		diffuse = vadd(diffuse, vscale(vmul(sp->diffuse, dl->colour), max0(vdot(N, L))));
+		v3 vl = vadd(view, L);
+		v3 H = vdivs(vl, vlength(vl));
+		specular = vadd(specular, vscale(vmul(sp->specular, dl->colour), powf_mode(cx, max0(vdot(N, H)), sp->power)));
+	}
 	v3 total = V(0, 0, 0);
 	total = vadd(total, ambient);
 	total = vadd(total, diffuse);
@@ -575,9 +587,12 @@ int sko_write_ppm(const char *path, int w, int h, const uint8_t *rgb)
  * and triangles; ambient_light accumulates; directional lights are parsed and
  * dropped; spherical_fog is skipped (UB in the reference); triangle indices are
  * read as floats. */
-int sko_scene_load(const char *path, sko_scene *out)
+int sko_scene_load(const char *path, sko_scene *out) { return sko_scene_load_ex(path, 0, out); }
+
+int sko_scene_load_ex(const char *path, int strict, sko_scene *out)
 {
 	memset(out, 0, sizeof *out);
+	int cap_d = 0;
 	FILE *fp = fopen(path, "r");
 	if(!fp) return 1;
 	out->film_w = 1920; out->film_h = 1080; out->max_depth_parsed = 1; /* scene.h:15,26 */
@@ -652,7 +667,21 @@ int sko_scene_load(const char *path, sko_scene *out)
 			mat.transmissive = V(m[10], m[11], m[12]);
 			mat.ior = m[13];
 		}
-		else if(!strcmp(command, "directional_light")) out->n_directional_dropped++;
+		else if(!strcmp(command, "directional_light"))
+		{
+			if(!strict) out->n_directional_dropped++; /* scene.cpp:139-163: built, echoed, never pushed */
+			else
+			{
+				float r = 0, g = 0, b = 0, x = 0, y = 0, z = 0;
+				sscanf(line, "directional_light %f %f %f %f %f %f", &r, &g, &b, &x, &y, &z);
+				if(r > 1) r = 1; /* scene.cpp:143-154 */
+				if(g > 1) g = 1;
+				if(b > 1) b = 1;
+				if(out->n_directional_lights == cap_d) { cap_d = cap_d ? cap_d * 2 : 8; out->directional_lights = realloc(out->directional_lights, sizeof(sko_directional_light) * cap_d); }
+				sko_directional_light dl = {V(x, y, z), V(r, g, b)};
+				out->directional_lights[out->n_directional_lights++] = dl;
+			}
+		}
 		else if(!strcmp(command, "point_light"))
 		{
 			float r = 0, g = 0, b = 0, x = 0, y = 0, z = 0;
@@ -687,5 +716,6 @@ void sko_scene_free(sko_scene *s)
 	free(s->spheres);
 	free(s->triangles);
 	free(s->point_lights);
+	free(s->directional_lights);
 	memset(s, 0, sizeof *s);
 }

@@ -31,6 +31,8 @@ typedef struct { sko_vec3 v0, v1, v2; } sko_triangle;
 
 /* reference: lights.h:19 */
 typedef struct { sko_vec3 position, colour; } sko_point_light;
+/* reference: lights.h:13 */
+typedef struct { sko_vec3 direction, colour; } sko_directional_light;
 
 /* reference: scene.h:13-28 (+ camera.h:8-32) */
 typedef struct {
@@ -46,6 +48,9 @@ typedef struct {
 	int n_directional_dropped;     /* scene.cpp:139-163 builds the light and never pushes it */
 	int n_fog_skipped;             /* scene.cpp:207-212 is UB; pinned as "ignored" */
 	int n_unknown, n_bad_triangles;
+	/* --strict-scn only (sko_scene_load_ex): the directional lights scene.cpp:139-163 builds and forgets, pushed */
+	int n_directional_lights;
+	sko_directional_light *directional_lights;
 } sko_scene;
 
 enum { SKO_RNG_GLIBC_REPLAY = 0, SKO_RNG_COUNTER = 1 };
@@ -71,6 +76,10 @@ typedef struct {
  * [2]=shadow casts (unique, i.e. one per light per hit), [3]=sphere tests,
  * [4]=triangle tests.  May be NULL. */
 int sko_scene_load(const char *path, sko_scene *out);
+/* strict != 0: the loader as its author evidently meant it: directional lights are kept (colour
+ * clamped to <= 1 as scene.cpp:143-154 does) and shaded by blinn_phong.h:77-85,122-131 with the shadow test of
+ * utils.h:60-76.  film_resolution and max_depth are parsed either way; honouring them is the caller's business. */
+int sko_scene_load_ex(const char *path, int strict, sko_scene *out);
 void sko_scene_free(sko_scene *s);
 int sko_render(const sko_scene *scene, const sko_options *opt, uint8_t *rgb, float *rgbf, uint64_t *stats);
 

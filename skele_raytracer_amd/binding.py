@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # every symbol include/skr.h declares (tests/test_abi.py checks the library exports them)
 EXPORTED_SYMBOLS = [
-    "skr_scene_create_from_scn", "skr_scene_create_from_arrays", "skr_scene_destroy", "skr_scene_get_info",
+    "skr_scene_create_from_scn", "skr_scene_create_from_scn_ex", "skr_scene_create_from_arrays", "skr_scene_destroy", "skr_scene_get_info",
     "skr_scene_get_arrays", "skr_scene_get_culling", "skr_options_default", "skr_radiance_ray_count", "skr_device_count",
     "skr_renderer_create", "skr_renderer_destroy", "skr_render_tiles", "skr_tile_count", "skr_render_rows",
     "skr_renderer_read_counters", "skr_renderer_read_work", "skr_renderer_reload_switches", "skr_renderer_kernel_timing", "skr_renderer_kernel_ms", "skr_renderer_last_parent_count", "skr_renderer_last_level1_count", "skr_render_frame_host", "skr_write_ppm", "skr_last_error",
@@ -35,7 +35,7 @@ class CSceneInfo(C.Structure):
                 ("n_vertices", C.c_int32), ("n_directional_dropped", C.c_int32), ("n_fog_skipped", C.c_int32),
                 ("n_unknown", C.c_int32), ("n_bad_triangles", C.c_int32), ("film_width", C.c_int32),
                 ("film_height", C.c_int32), ("max_depth_parsed", C.c_int32), ("camera", C.c_float * 13),
-                ("background", C.c_float * 3), ("ambient", C.c_float * 3)]
+                ("background", C.c_float * 3), ("ambient", C.c_float * 3), ("n_directional_lights", C.c_int32)]
 
 
 def lib_path():
@@ -62,6 +62,7 @@ def lib():
     L = C.CDLL(path)
     vp = C.c_void_p
     L.skr_scene_create_from_scn.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.skr_scene_create_from_scn_ex.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(vp)]
     L.skr_scene_create_from_arrays.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, C.c_int32, vp, vp, vp, C.POINTER(vp)]
     L.skr_scene_destroy.argtypes = [vp]
     L.skr_scene_destroy.restype = None
@@ -200,10 +201,10 @@ class Scene:
         return Scene(h.value)
 
 
-def parse_scene(path, echo=False):
-    """Reference `Scene parseScene(std::string)` (scene.cpp:12)."""
+def parse_scene(path, echo=False, strict=False):
+    """Reference `Scene parseScene(std::string)` (scene.cpp:12); strict = SKR_SCN_STRICT (--strict-scn: directional lights kept)."""
     h = C.c_void_p()
-    _check(lib().skr_scene_create_from_scn(os.fsencode(path), int(echo), C.byref(h)), "skr_scene_create_from_scn")
+    _check(lib().skr_scene_create_from_scn_ex(os.fsencode(path), int(echo), 1 if strict else 0, C.byref(h)), "skr_scene_create_from_scn_ex")
     return Scene(h.value)
 
 

@@ -239,7 +239,7 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.background = f3{r->info.background[0], r->info.background[1], r->info.background[2]};
 	p.n_spheres = r->info.n_spheres;
 	p.n_tris = r->info.n_triangles;
-	p.n_lights = r->info.n_point_lights;
+	p.n_lights = r->info.n_point_lights + r->info.n_directional_lights; // (directional ones only under --strict-scn)
 	p.sph_geom = r->d_blob;
 	p.sph_amb = r->d_blob + r->off_amb;
 	p.sph_kd = r->d_blob + r->off_kd;

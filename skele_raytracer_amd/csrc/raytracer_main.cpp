@@ -22,6 +22,7 @@ int main(int argc, char *argv[])
 	bool visual = true; // utils.h:29; kept for compatibility: there is no SDL viewer, both values render on the GPU
 	bool quiet = false;
 	int device = 0, gpus = 1;
+	bool strict_scn = false, width_given = false, height_given = false, depth_given = false; // --strict-scn (new)
 	bool sharded = false; // --gpus given (even --gpus 1): the frame goes through the multi-GPU path
 	uint32_t tile_rows = 8;
 
@@ -63,6 +64,7 @@ int main(int argc, char *argv[])
 				return 0;
 			}
 			option.width = atoi(argv[i + 1]);
+			width_given = true;
 		}
 		if(!strcmp(argv[i], "--height"))
 		{
@@ -72,6 +74,7 @@ int main(int argc, char *argv[])
 				return 0;
 			}
 			option.height = atoi(argv[i + 1]);
+			height_given = true;
 		}
 		if(!strcmp(argv[i], "--depth"))
 		{
@@ -81,6 +84,7 @@ int main(int argc, char *argv[])
 				return 0;
 			}
 			option.max_depth = atoi(argv[i + 1]);
+			depth_given = true;
 		}
 		if(!strcmp(argv[i], "--parallel"))
 		{
@@ -111,6 +115,7 @@ int main(int argc, char *argv[])
 		if(!strcmp(argv[i], "--gpus") && has_next) { gpus = atoi(argv[i + 1]) > 0 ? atoi(argv[i + 1]) : 1; sharded = true; }           // new: the frame sharded over the first N devices
 		if(!strcmp(argv[i], "--tile-rows") && has_next) tile_rows = (uint32_t) (atoi(argv[i + 1]) > 0 ? atoi(argv[i + 1]) : 8);
 		if(!strcmp(argv[i], "--quiet")) quiet = true;
+		if(!strcmp(argv[i], "--strict-scn")) strict_scn = true;
 	}
 	if(!path)
 	{
@@ -124,10 +129,19 @@ int main(int argc, char *argv[])
 	}
 
 	skr_scene *scene = nullptr;
-	if(skr_scene_create_from_scn(path, quiet ? 0 : 1, &scene) != SKR_OK)
+	if(skr_scene_create_from_scn_ex(path, quiet ? 0 : 1, strict_scn ? SKR_SCN_STRICT : 0u, &scene) != SKR_OK)
 	{
 		printf("%s\n", skr_last_error()); // scene.cpp:24-25: message, exit(0)
 		return 0;
+	}
+	if(strict_scn)
+	{ // the .scn's own film_resolution (scene.cpp:105-109) and max_depth (:192-198) hold unless the command line says otherwise
+	  // (the reference parses both and then overrides / never reads them: main.cpp:393-395, scene.h:26)
+		skr_scene_info info;
+		skr_scene_get_info(scene, &info);
+		if(!width_given && info.film_width > 0) option.width = info.film_width;
+		if(!height_given && info.film_height > 0) option.height = info.film_height;
+		if(!depth_given && info.max_depth_parsed > 0) option.max_depth = info.max_depth_parsed;
 	}
 	// utils.h:35-38 Options::to_string
 	printf("\n\nMonte carlo: %d\nvisual display: %d\nfov: %f\nnum paths traced: %d\nsupersample grid size: %d\nmax depth: %d\n",

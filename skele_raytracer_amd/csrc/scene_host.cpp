@@ -64,12 +64,20 @@ void skr_scene::finalize()
 		sph_kd[i] = {s[7], s[8], s[9], 0.0f};
 		sph_ks[i] = {s[10], s[11], s[12], 0.0f};
 	}
-	lights.resize((size_t) nl * 2);
+	// point lights first, then (--strict-scn) the directional ones: the order blinn_phong.h:50-85 / :95-131 adds them in
+	const int nd = (int) (raw_directional_lights.size() / 6);
+	lights.resize((size_t) (nl + nd) * 2);
 	for(int i = 0; i < nl; i++)
 	{
 		const float *l = &raw_point_lights[(size_t) i * 6];
 		lights[2 * i] = {l[0], l[1], l[2], 0.0f};
 		lights[2 * i + 1] = {l[3], l[4], l[5], 0.0f};
+	}
+	for(int i = 0; i < nd; i++)
+	{
+		const float *l = &raw_directional_lights[(size_t) i * 6];
+		lights[2 * (nl + i)] = {l[0], l[1], l[2], 1.0f}; // .w = 1: a direction, not a position (shade_common.h light_term)
+		lights[2 * (nl + i) + 1] = {l[3], l[4], l[5], 0.0f};
 	}
 	// The triangle walk only answers "does any triangle accept this ray before tmin" (raytrace.h:168-176 turns
 	// any such hit black), so the order of tris[] is free: store the triangles along a Morton curve through the
@@ -441,7 +449,7 @@ static void set_camera(skr_scene_info &info, const float p[3], const float d[3],
 	info.camera[12] = ha;
 }
 
-int skr_parse_scn(const std::string &path, bool echo, skr_scene &sc)
+int skr_parse_scn(const std::string &path, bool echo, bool strict, skr_scene &sc)
 {
 	FILE *fp = fopen(path.c_str(), "r");
 	if(!fp)
@@ -450,6 +458,7 @@ int skr_parse_scn(const std::string &path, bool echo, skr_scene &sc)
 		return SKR_ERR_IO;
 	}
 	sc = skr_scene();
+	sc.strict = strict;
 	skr_scene_info &info = sc.info;
 	info.film_width = 1920; // scene.h:15
 	info.film_height = 1080;
@@ -556,7 +565,15 @@ int skr_parse_scn(const std::string &path, bool echo, skr_scene &sc)
 			float v[6] = {0};
 			read_floats(args, v, 6);
 			if(echo) printf("directional light colour (%f, %f, %f), direction (%f, %f, %f)\n", v[0], v[1], v[2], v[3], v[4], v[5]);
-			info.n_directional_dropped++; // scene.cpp:157-163: built, never pushed
+			if(!strict) info.n_directional_dropped++; // scene.cpp:157-163: built, never pushed
+			else
+			{ // --strict-scn: pushed, with the clamp of scene.cpp:143-154
+				for(int k = 0; k < 3; k++)
+					if(v[k] > 1) v[k] = 1;
+				const float rec[6] = {v[3], v[4], v[5], v[0], v[1], v[2]}; // file order is colour then direction
+				sc.raw_directional_lights.insert(sc.raw_directional_lights.end(), rec, rec + 6);
+				info.n_directional_lights++;
+			}
 		}
 		else if(cmd == "point_light")
 		{
@@ -605,7 +622,9 @@ int skr_parse_scn(const std::string &path, bool echo, skr_scene &sc)
 
 extern "C" {
 
-int skr_scene_create_from_scn(const char *path, int echo, skr_scene **out)
+int skr_scene_create_from_scn(const char *path, int echo, skr_scene **out) { return skr_scene_create_from_scn_ex(path, echo, 0, out); }
+
+int skr_scene_create_from_scn_ex(const char *path, int echo, uint32_t flags, skr_scene **out)
 {
 	if(!path || !out)
 	{
@@ -613,7 +632,7 @@ int skr_scene_create_from_scn(const char *path, int echo, skr_scene **out)
 		return SKR_ERR_ARG;
 	}
 	skr_scene *sc = new skr_scene();
-	int rc = skr_parse_scn(path, echo != 0, *sc);
+	int rc = skr_parse_scn(path, echo != 0, (flags & SKR_SCN_STRICT) != 0, *sc);
 	if(rc != SKR_OK)
 	{
 		delete sc;

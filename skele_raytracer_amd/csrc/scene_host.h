@@ -21,6 +21,8 @@ struct skr_scene {
 	std::vector<float> raw_spheres;      // [n][14] centre radius ambient diffuse specular power
 	std::vector<float> raw_triangles;    // [n][9]  v0 v1 v2
 	std::vector<float> raw_point_lights; // [n][6]  position colour
+	std::vector<float> raw_directional_lights; // [n][6] direction colour — --strict-scn only (scene.cpp:139-163 drops them)
+	bool strict = false;                 // parsed with SKR_SCN_STRICT
 	skr_scene_info info{};
 
 	// SoA arrays as uploaded (built by finalize())
@@ -28,7 +30,7 @@ struct skr_scene {
 	std::vector<skr_f4> sph_amb;  // ambient_light.colour * material.ambient (blinn_phong.h:15), .w = phong power
 	std::vector<skr_f4> sph_kd;   // material.diffuse
 	std::vector<skr_f4> sph_ks;   // material.specular
-	std::vector<skr_f4> lights;   // [2*i] position, [2*i+1] colour
+	std::vector<skr_f4> lights;   // [2*i] position (.w = 0) or, behind the point lights, direction (.w = 1: --strict-scn), [2*i+1] colour
 	std::vector<skr_f4> tris;     // [3*i] v0, [3*i+1] v1-v0, [3*i+2] v2-v0 (utils.h:183-184 subtractions)
 	// the culling data of the triangle walk: a tree, depth-first with skip links, three float4 per node — {centre, R^2}
 	// {axis / kappa, R_tight^2} {skip, first chunk, chunk count, height} (ints) — + one pad node, then two float4 per
@@ -47,6 +49,6 @@ struct skr_scene {
 };
 
 // scene.cpp:12-227 replacement.  Returns SKR_OK or SKR_ERR_IO.
-int skr_parse_scn(const std::string &path, bool echo, skr_scene &out);
+int skr_parse_scn(const std::string &path, bool echo, bool strict, skr_scene &out);
 
 void skr_set_error(const char *fmt, ...);

@@ -262,9 +262,16 @@ struct LightTerm { // the per-light quantities of blinn_phong.h:67-72 / :100-117
 SKR_DEV LightTerm light_term(const SceneView &sv, int i, f3 P)
 {
 	LightTerm t;
-	const f3 lp = ld3(sv.lights[2 * i]);
+	const float4 lp4 = sv.lights[2 * i];
 	t.lc = ld3(sv.lights[2 * i + 1]);
-	const f3 to_l = lp - P;
+	if(lp4.w != 0.0f)
+	{ // a directional light (--strict-scn only; blinn_phong.h:81-82,126-128): L = normalize(direction) and no 1/d^2 — len = 1 makes
+	  // the intensity factor of the point-light expression exactly 1, and x * 1 == x
+		t.L = normalize3(ld3(lp4));
+		t.len = 1.0f;
+		return t;
+	}
+	const f3 to_l = ld3(lp4) - P;
 	t.len = sk_sqrtf(sqr3(to_l));
 	t.L = to_l * sk_divf(1.0f, t.len);
 	return t;

@@ -39,6 +39,7 @@ def _parse(argv):
     """main.cpp:246-379 as bin/raytracer restates it: flags anywhere, the value is the next token read with atoi / atof
     (`--width abc` is width 0, not a usage error); only a MISSING value is a usage error — and for --gillum a warning."""
     opt = dict(path=None, output=None, width=1920, height=1080, fov=60.0, gillum=None, jsample=None, depth=3, shadow=False, seed=1, tile_rows=8)
+    given = set()  # --strict-scn: the .scn's film_resolution / max_depth hold for what the command line leaves open
 
     def value(i, kind, what):
         if i + 1 >= len(argv):
@@ -52,8 +53,10 @@ def _parse(argv):
             opt["output"] = value(i, str, "output path must be passed after --output")
         elif a == "--width":
             opt["width"] = value(i, _atoi, "width takes an int after flag for the width")
+            given.add("width")
         elif a == "--height":
             opt["height"] = value(i, _atoi, "height takes an int after flag for the width")
+            given.add("height")
         elif a == "--fov":
             opt["fov"] = value(i, _atof, "fov takes a float (degrees) after flag for the field of view")
         elif a == "--gillum":
@@ -67,14 +70,19 @@ def _parse(argv):
             opt["depth"] = value(i, _atoi, "depth takes a positive int after flag for the max depth")
             if opt["depth"] <= 0:
                 raise ValueError("depth takes a positive int after flag for the max depth")
+            given.add("depth")
         elif a == "--shadow":
             opt["shadow"] = True
+        elif a == "--strict-scn":
+            opt["strict_scn"] = True
         elif a == "--seed":
             opt["seed"] = value(i, _atoi, "seed takes an int")
         elif a == "--tile-rows":
             opt["tile_rows"] = value(i, _atoi, "tile-rows takes a positive int")
     if opt["tile_rows"] <= 0:
         raise ValueError("tile-rows takes a positive int")
+    if opt.get("strict_scn"):
+        opt["_given"] = given
     if opt["path"] is None:
         raise ValueError("no scene file was passed. Pass with --path path_to_scn")
     if opt["output"] is None:
@@ -115,13 +123,21 @@ def main(argv=None):
         else:
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
     try:
-        scene = skr.parse_scene(o["path"])
+        scene = skr.parse_scene(o["path"], strict=bool(o.get("strict_scn")))
     except skr.SkrError as e:
         if rank == 0:
             print(str(e))  # scene.cpp:24: "Can't open file" on stdout, exit(0)
         if world > 1:
             dist.destroy_process_group()
         return 0
+    if o.get("strict_scn"):  # as bin/raytracer --strict-scn: the .scn's film_resolution and max_depth for what argv leaves open
+        info = scene.info
+        if "width" not in o["_given"] and info.film_width > 0:
+            o["width"] = info.film_width
+        if "height" not in o["_given"] and info.film_height > 0:
+            o["height"] = info.film_height
+        if "depth" not in o["_given"] and info.max_depth_parsed > 0:
+            o["depth"] = info.max_depth_parsed
     r = skr.Renderer(scene, local_rank)
     kw = dict(fov=o["fov"], depth=o["depth"], shadow=o["shadow"], seed=o["seed"])
     if o["gillum"] is not None:

@@ -40,7 +40,7 @@ def manifest():
 
 def args_to_kwargs(args):
     """ref_render argument list (manifest.json) -> keyword arguments of the python bindings."""
-    kw = dict(width=1920, height=1080, fov=60.0, gillum=None, jsample=0, depth=3, shadow=False, seed=1)
+    kw = dict(width=1920, height=1080, fov=60.0, gillum=None, jsample=0, depth=3, shadow=False, seed=1)  # (+ strict=True for --strict)
     it = iter(args)
     for a in it:
         if a == "--width":
@@ -59,6 +59,8 @@ def args_to_kwargs(args):
             kw["seed"] = int(next(it))
         elif a == "--shadow":
             kw["shadow"] = True
+        elif a == "--strict":  # ref_driver.cpp: the directional lights pushed (--strict-scn)
+            kw["strict"] = True
         elif a == "--parallel-entry":  # main.cpp:21-24
             kw.update(width=640, height=480, depth=1, jsample=0)
     return kw

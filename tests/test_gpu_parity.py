@@ -26,15 +26,16 @@ def gpu():
 _renderers = {}
 
 
-def renderer(scn):
-    if scn not in _renderers:
-        sc = skr.parse_scene(scene_path(scn))
-        _renderers[scn] = (sc, skr.Renderer(sc))
-    return _renderers[scn][1]
+def renderer(scn, strict=False):
+    key = (scn, bool(strict))
+    if key not in _renderers:
+        sc = skr.parse_scene(scene_path(scn), strict=strict)  # strict: --strict-scn, the directional lights kept
+        _renderers[key] = (sc, skr.Renderer(sc))
+    return _renderers[key][1]
 
 
-def gpu_render(scn, w, h, want_float=True, **kw):
-    r = renderer(scn)
+def gpu_render(scn, w, h, want_float=True, strict=False, **kw):
+    r = renderer(scn, strict)
     r.counters(reset=True)  # renderers are cached across tests: drop what earlier launches accumulated
     rgb, rgbf = r.render(skr.Options(w, h, **kw), want_float=want_float)
     import torch
@@ -80,6 +81,12 @@ CASES = [
     ("spheres2_gi300_d2", "spheres2.scn", 16, 9, dict(gillum=300, depth=2, seed=2)),           # beyond it: per-pixel kernel
     ("spheres1_gi7_js2", "spheres1.scn", 64, 36, dict(gillum=7, jsample=2, shadow=True, seed=21)),
     ("tiny_1x1", "spheres2.scn", 1, 1, dict(gillum=4, shadow=True)),
+    # --strict-scn: spheres2.scn's two directional lights pushed and shaded (blinn_phong.h:77-85,122-131; shadow test utils.h:60-76)
+    ("strict_spheres2_shadow", "spheres2.scn", 240, 135, dict(shadow=True, strict=True)),
+    ("strict_spheres2_noshadow_js2", "spheres2.scn", 160, 90, dict(jsample=2, seed=3, strict=True)),
+    ("strict_spheres2_gi8_shadow", "spheres2.scn", 160, 90, dict(gillum=8, shadow=True, seed=11, strict=True)),
+    ("strict_spheres2_gi3_d4", "spheres2.scn", 64, 36, dict(gillum=3, depth=4, shadow=True, seed=5, strict=True)),
+    ("strict_spheres1_same_as_default", "spheres1.scn", 96, 54, dict(gillum=4, shadow=True, seed=2, strict=True)),  # no directional light in the file
     ("tall_3x70", "spheres1.scn", 3, 70, dict(jsample=2, shadow=True)),
 ]
 
@@ -89,6 +96,9 @@ def test_gpu_matches_oracle_bit_for_bit(gpu, oracle, name, scn, w, h, kw):
     g_rgb, g_f, cnt = gpu_render(scn, w, h, **kw)
     o_rgb, o_f, st = oracle.render(scene_path(scn), w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, **kw)
     compare(g_rgb, g_f, o_rgb, o_f, name)
+    if kw.get("strict") and scn == "spheres2.scn":  # and the lights do change the picture
+        d_rgb, _, _ = gpu_render(scn, w, h, **dict(kw, strict=False))
+        assert (d_rgb != g_rgb).mean() > 0.001  # (both lights point downwards: only surfaces facing down see them)
     # the work counters are part of the metric: they must agree with the oracle's count
     assert cnt["radiance_rays"] == int(st[0]) and cnt["sphere_hits"] == int(st[1])
     if kw.get("shadow"):
@@ -203,6 +213,36 @@ def test_cli_drop_in_writes_the_same_ppm(gpu, oracle, tmp_path):
     assert res.returncode == 0 and "depth takes a positive int" in res.stderr
     res = subprocess.run([exe, "--path", str(tmp_path / "nope.scn"), "--output", out], capture_output=True, text=True, timeout=60)
     assert res.returncode == 0 and "Can't open file" in res.stdout
+
+
+def test_cli_strict_scn(gpu, oracle, tmp_path):
+    """`raytracer --strict-scn` (both front ends): the directional lights are shaded, and the .scn's own film_resolution and
+    max_depth hold for whatever the command line leaves open (spheres2.scn: max_depth 2; test.scn: film_resolution 1024 768,
+    max_depth 10) — the reference parses all three and then drops / overrides / never reads them."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT, read_ppm_bytes
+    exe = os.path.join(ROOT, "bin", "raytracer")
+    out = str(tmp_path / "strict.ppm")
+    base = ["--output", out, "--path", scene_path("spheres2.scn"), "--width", "160", "--height", "90", "--gillum", "4", "--shadow", "--seed", "7", "--quiet"]
+    subprocess.run([exe] + base + ["--strict-scn"], check=True, capture_output=True, timeout=120)
+    got = read_ppm_bytes(open(out, "rb").read())
+    want, _, _ = oracle.render(scene_path("spheres2.scn"), 160, 90, gillum=4, shadow=True, seed=7, depth=2, strict=True)  # the file's max_depth 2
+    assert np.array_equal(got, want)
+    subprocess.run([exe] + base + ["--strict-scn", "--depth", "3"], check=True, capture_output=True, timeout=120)  # argv wins
+    want3, _, _ = oracle.render(scene_path("spheres2.scn"), 160, 90, gillum=4, shadow=True, seed=7, depth=3, strict=True)
+    assert np.array_equal(read_ppm_bytes(open(out, "rb").read()), want3) and not np.array_equal(want3, want)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    res = subprocess.run([sys.executable, "-m", "skele_raytracer_amd.render_cli"] + base[:-1] + ["--strict-scn"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr
+    assert np.array_equal(read_ppm_bytes(open(out, "rb").read()), want)
+    res = subprocess.run([exe, "--output", out, "--path", scene_path("test.scn"), "--strict-scn", "--shadow", "--quiet"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    got = read_ppm_bytes(open(out, "rb").read())
+    assert got.shape == (768, 1024, 3)
+    want, _, _ = oracle.render(scene_path("test.scn"), 1024, 768, shadow=True, depth=10, strict=True, y0=300, y1=340)
+    assert np.array_equal(got[300:340], want)
 
 
 def _write_synthetic_scn(path, rng, n_spheres, n_lights, n_tris):

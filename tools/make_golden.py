@@ -47,6 +47,16 @@ CASES = [
     ("test_gi4", "test.scn", ["--width", "80", "--height", "60", "--shadow", "--gillum", "4", "--seed", "3"]),
     ("bear_shadow", "bear.scn", ["--width", "160", "--height", "120", "--shadow"]),
     ("dragon_160x120", "dragon.scn", ["--width", "160", "--height", "120", "--depth", "1"]),
+    # round 2: a deep, narrow tree (--depth beyond the old GPU cap of 6; main.cpp:318-329 takes any positive depth)
+    ("spheres2_gi2_d8", "spheres2.scn", ["--width", "48", "--height", "27", "--shadow", "--gillum", "2", "--depth", "8", "--seed", "8"]),
+    # the headline GI case under a second srand() seed: what two independent Monte-Carlo frames of the REFERENCE look like
+    # against each other (tests/test_statistics.py compares the counter-RNG frame with both)
+    ("spheres2_gi16_shadow_seed2", "spheres2.scn", ["--width", "160", "--height", "90", "--shadow", "--gillum", "16", "--seed", "777"]),
+    # --strict-scn: ref_driver.cpp --strict pushes the directional lights scene.cpp:139-163 parses and drops;
+    # the reference's own blinn_phong.h:77-85,122-131 and utils.h:60-76 shade them (spheres2.scn has two)
+    ("spheres2_strict_shadow", "spheres2.scn", ["--width", "160", "--height", "90", "--shadow", "--strict"]),
+    ("spheres2_strict_noshadow", "spheres2.scn", ["--width", "160", "--height", "90", "--strict"]),
+    ("spheres2_strict_gi4", "spheres2.scn", ["--width", "96", "--height", "54", "--shadow", "--gillum", "4", "--strict", "--seed", "3"]),
 ]
 
 
@@ -78,7 +88,7 @@ def main():
     for name, scn, args in CASES:
         cmd = [BIN, "--path", os.path.join(REF, "scenes", scn), "--output", tmp] + args
         print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL)  # (blinn_phong.h:124 prints a line per specular call once a directional light exists)
         dst = os.path.join(GOLD, "ref_%s.ppm.gz" % name)
         gz_write(tmp, dst)
         manifest["cases"][name] = {"scene": scn, "args": args, "sha256_uncompressed": sha(tmp), "file": os.path.basename(dst)}
