@@ -91,6 +91,8 @@ def lib():
         L.sko_counter_jitter.restype = C.c_float
         L.sko_counter_draws.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.sko_primary_direction.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float)]
+        L.sko_primary_direction.restype = None
         L.sko_write_ppm.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
         L.sko_write_ppm.restype = C.c_int
         _lib = L
@@ -109,6 +111,13 @@ class OracleScene:
             lib().sko_scene_free(C.byref(self.s))
         except Exception:
             pass
+
+
+def primary_direction(scene, width, height, fov, x, y, jitter, r=0.0):
+    """The primary ray direction the render loop forms (skr_oracle.h sko_primary_direction)."""
+    out = (C.c_float * 3)()
+    lib().sko_primary_direction(C.byref(scene.s), width, height, fov, x, y, int(bool(jitter)), r, out)
+    return np.array(out[:], np.float32)
 
 
 def host_cores():

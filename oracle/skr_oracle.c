@@ -498,6 +498,34 @@ uint8_t sko_quantise(float c)
 	return (uint8_t) (int32_t) s;
 }
 
+/* The primary direction of one sample: main.cpp:146-155 (jitter: one draw r for both axes, all-float) or :170-174 (pixel centre:
+ * u and v formed in double).  ONE definition: the render loop below calls it, and it is exported so that a test can compare it
+ * with the expressions of main.cpp evaluated independently (tests/test_statistics.py) — the jitter branch of
+ * oracle/ref_driver.cpp is a hand restatement that no reference-held fixture covers. */
+static inline v3 primary_direction(const sko_scene *scene, int x, int y, int jitter, float r, float inv_width, float inv_height, float aspect_ratio, float angle)
+{
+	float u, v;
+	if(jitter)
+	{
+		u = (2 * ((x + r) * inv_width) - 1) * angle * aspect_ratio;
+		v = (1 - 2 * ((y + r) * inv_height)) * angle;
+	}
+	else
+	{
+		u = (float) ((2 * ((x + 0.5) * inv_width) - 1) * angle * aspect_ratio);
+		v = (float) ((1 - 2 * ((y + 0.5) * inv_height)) * angle);
+	}
+	return vadd(vadd(scene->cam_dir, vscale(scene->cam_right, u)), vscale(scene->cam_up, v));
+}
+
+void sko_primary_direction(const sko_scene *scene, int width, int height, float fov, int x, int y, int jitter, float r, float out[3])
+{
+	const v3 d = primary_direction(scene, x, y, jitter, r, 1 / (float) width, 1 / (float) height, width / (float) height, (float) tan(M_PI * 0.5 * fov / 180.));
+	out[0] = d.x;
+	out[1] = d.y;
+	out[2] = d.z;
+}
+
 int sko_render(const sko_scene *scene, const sko_options *opt, uint8_t *rgb, float *rgbf, uint64_t *stats)
 {
 	const int W = opt->width, H = opt->height;
@@ -543,9 +571,7 @@ int sko_render(const sko_scene *scene, const sko_options *opt, uint8_t *rgb, flo
 				{
 					cx.aa = (uint32_t) s;
 					float r = (opt->rng_mode == SKO_RNG_GLIBC_REPLAY) ? (float) rand() / (float) RAND_MAX : sko_counter_jitter(opt->seed, cx.pixel, cx.aa);
-					float u = (2 * ((x + r) * inv_width) - 1) * angle * aspect_ratio;
-					float v = (1 - 2 * ((y + r) * inv_height)) * angle;
-					v3 dir = vadd(vadd(scene->cam_dir, vscale(scene->cam_right, u)), vscale(scene->cam_up, v));
+					v3 dir = primary_direction(scene, x, y, 1, r, inv_width, inv_height, aspect_ratio, angle);
 					px = vadd(px, shade(&cx, scene->cam_pos, dir, opt->max_depth, 0));
 				}
 				px = vdivs(px, (float) (g * g));
@@ -553,9 +579,7 @@ int sko_render(const sko_scene *scene, const sko_options *opt, uint8_t *rgb, flo
 			else
 			{ /* main.cpp:168-182: pixel centre, u and v formed in double */
 				cx.aa = 0;
-				float u = (float) ((2 * ((x + 0.5) * inv_width) - 1) * angle * aspect_ratio);
-				float v = (float) ((1 - 2 * ((y + 0.5) * inv_height)) * angle);
-				v3 dir = vadd(vadd(scene->cam_dir, vscale(scene->cam_right, u)), vscale(scene->cam_up, v));
+				v3 dir = primary_direction(scene, x, y, 0, 0.0f, inv_width, inv_height, aspect_ratio, angle);
 				px = shade(&cx, scene->cam_pos, dir, opt->max_depth, 0);
 			}
 			if(y >= opt->y0)

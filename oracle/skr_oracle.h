@@ -94,6 +94,9 @@ uint8_t sko_quantise(float c);
 void sko_basis(const float n[3], float nt[3], float nb[3]);
 void sko_counter_draws(uint64_t seed, uint32_t pixel, uint32_t aa, uint32_t parent_node, uint32_t child, float *r1, float *r2);
 float sko_counter_jitter(uint64_t seed, uint32_t pixel, uint32_t aa);
+/* The primary ray direction the render loop forms for pixel (x, y): main.cpp:146-155 with the draw r (jitter != 0) or
+ * :170-174 at the pixel centre.  The loop calls this very function. */
+void sko_primary_direction(const sko_scene *scene, int width, int height, float fov, int x, int y, int jitter, float r, float out[3]);
 int sko_write_ppm(const char *path, int w, int h, const uint8_t *rgb);
 
 #ifdef __cplusplus
