@@ -6,9 +6,10 @@
 //
 //   skr_primary_kernel   (render_wave.hip) primary rays + direct light; every sphere hit becomes a level-0 node
 //   skr_trace_kernel     one lane per sibling pair of a node: traces the two child rays (one Philox call, one (e, c)
-//                        per sphere for both); per child one index word — r1 (miss: finalize recomputes
-//                        r1 background / pdf), IDX_BLACK (triangle, :221-224) or IDX_HIT | record — and per sphere
-//                        hit a 32-byte record appended to one of 64 regions (ballot ranks + one atomic per wave)
+//                        per sphere for both); per pair one 16-bit code (hit / triangle flags and the ranks of its hits among
+//                        the wave's: finalize finds the records from them and the wave's 8-byte header, and draws r1 of
+//                        a miss again from the same Philox counter) and per sphere
+//                        hit a 16-byte record (parent, sphere, child, the two draws) appended to one of 64 regions (ballot ranks + one atomic per wave)
 //   skr_activate_kernel  (depth >= 4 only) one lane per record: shades the hit (:194-207) and writes it as a node of
 //                        the next level, which the trace kernel then expands
 //   skr_leaf_kernel2     persistent waves, one unit = 64 records of the last-but-one level, ONE LANE PER RECORD: the 64
@@ -18,7 +19,7 @@
 //                        windows (one round each) until they are added, strictly in child order (:130), to the
 //                        lane's running sum.  Depth 2: the units are the level-0 nodes themselves and the pixels are
 //                        written here.
-//   skr_finalize_kernel2 one lane per node, deepest level first: the N terms in child order from the index words,
+//   skr_finalize_kernel2 one lane per node, deepest level first: the N terms in child order from the pair codes,
 //                        (direct/pi + 2 indirect) * kd (:213), times r1/pdf into the parent's level — or the pixel
 //
 // Every float operation and every order of summation is the reference's (DESIGN.md "Arithmetic spec"); only the
@@ -32,10 +33,12 @@
 
 namespace {
 
-constexpr uint32_t IDX_HIT = 0x80000000u;   // | record index (region * rc_cap + position)
-constexpr uint32_t IDX_BLACK = 0x7fffffffu; // the child hit a triangle: (0 * r1) / pdf
-constexpr int NQ_CAP = 128;                 // leaf-hit ring: <= 63 left over + 64 pushed
-constexpr int NQ_F = 7;                     // dwords per entry: d.xyz, b, D, ids, r1
+// One 16-bit code per sibling pair tells finalize what became of its two children; their record indices follow from the trace
+// wave's base (one 8-byte header per 64 pairs) and the ranks in the code, their r1 from the same Philox call the trace made.
+constexpr uint32_t PC_HIT0 = 1u, PC_HIT1 = 2u, PC_BLACK0 = 4u, PC_BLACK1 = 8u; // | rank of child 2j among the wave's even hits << 4 | rank of child 2j+1 among its odd hits << 10
+constexpr int NQ_CAP = 176;                 // leaf-hit ring: <= NQ_PRE left over when a round starts + the 128 hits it can add
+constexpr int NQ_PRE = NQ_CAP - 128;        // more than that waiting at the start of a round: one (>= 3/4 full) batch is shaded first
+constexpr int NQ_F = 5;                     // dwords per entry: d.xyz, ids, r1 (b and D of utils.h:116-118 are formed again from d when the hit is shaded)
 constexpr int NWIN = 4;                     // slot windows (rounds whose contributions may still be waiting for their hits' shading)
 constexpr int WIN_FLOATS = 2 * 3 * 64;      // [child 0|1][component][lane]
 constexpr int LEAF2_WAVE_FLOATS = NQ_CAP * NQ_F + NWIN * WIN_FLOATS;
@@ -116,8 +119,8 @@ __global__ __launch_bounds__(256) void skr_trace_kernel(const RenderParams p)
 	const bool second = valid && 2u * j + 1u < N;
 	Counters cn{0, 0, 0};
 	bool hit0 = false, hit1 = false;
-	float4 r0a = make_float4(0, 0, 0, 0), r0b = r0a, r1a = r0a, r1b = r0a;
-	uint32_t w0 = IDX_BLACK, w1 = IDX_BLACK;
+	float4 rec0 = make_float4(0, 0, 0, 0), rec1 = rec0;
+	bool black0 = false, black1 = false;
 	if(valid)
 	{
 		const float4 *row = p.nd_src + (size_t) node * p.nd_src_stride;
@@ -134,17 +137,12 @@ __global__ __launch_bounds__(256) void skr_trace_kernel(const RenderParams p)
 		const RayPair rp = make_pair(d0, d1);
 		BestState s0, s1;
 		closest_pair_deferred(sv, co, d0, d1, second, rp, s0, s1);
-		bool black;
-		hit0 = classify_child(sv, co, d0, rp.two_a.x, rp.four_a.x, s0, black);
-		w0 = black ? IDX_BLACK : __float_as_uint(q1a);
-		r0a = make_float4(d0.x, d0.y, d0.z, s0.b);
-		r0b = make_float4(s0.D, q1a, __uint_as_float(node), __uint_as_float((uint32_t) (s0.best & 0xffff) | ((2u * j) << 16)));
+		hit0 = classify_child(sv, co, d0, rp.two_a.x, rp.four_a.x, s0, black0);
+		rec0 = make_float4(__uint_as_float(node), __uint_as_float((uint32_t) (s0.best & 0xffff) | ((2u * j) << 16)), q1a, q2a);
 		if(second)
 		{
-			hit1 = classify_child(sv, co, d1, rp.two_a.y, rp.four_a.y, s1, black);
-			w1 = black ? IDX_BLACK : __float_as_uint(q1b);
-			r1a = make_float4(d1.x, d1.y, d1.z, s1.b);
-			r1b = make_float4(s1.D, q1b, __uint_as_float(node), __uint_as_float((uint32_t) (s1.best & 0xffff) | ((2u * j + 1u) << 16)));
+			hit1 = classify_child(sv, co, d1, rp.two_a.y, rp.four_a.y, s1, black1);
+			rec1 = make_float4(__uint_as_float(node), __uint_as_float((uint32_t) (s1.best & 0xffff) | ((2u * j + 1u) << 16)), q1b, q2b);
 		}
 	}
 	// append the wave's hits to its region: rank by ballot, one atomic per wave
@@ -157,23 +155,12 @@ __global__ __launch_bounds__(256) void skr_trace_kernel(const RenderParams p)
 		if(lane == 0) base = atomicAdd(lc_count(p.rc_ctr, region), n0h + n1h);
 		base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
 	}
-	if(hit0)
-	{
-		const uint32_t pos = base + (uint32_t) lanes_below(m0), rec = region * p.rc_cap + pos;
-		float4 *dst = p.rc + (size_t) rec * 2;
-		dst[0] = r0a;
-		dst[1] = r0b;
-		w0 = IDX_HIT | rec;
-	}
-	if(hit1)
-	{
-		const uint32_t pos = base + n0h + (uint32_t) lanes_below(m1), rec = region * p.rc_cap + pos;
-		float4 *dst = p.rc + (size_t) rec * 2;
-		dst[0] = r1a;
-		dst[1] = r1b;
-		w1 = IDX_HIT | rec;
-	}
-	if(valid) *reinterpret_cast<uint2 *>(p.ix + (size_t) node * p.ix_stride + 2u * j) = make_uint2(w0, w1);
+	const uint32_t rec_base = region * p.rc_cap + base; // the even children's hits first, then the odd ones
+	const uint32_t rank0 = (uint32_t) lanes_below(m0), rank1 = (uint32_t) lanes_below(m1);
+	if(hit0) p.rc[rec_base + rank0] = rec0;
+	if(hit1) p.rc[rec_base + n0h + rank1] = rec1;
+	if(valid) p.ix16[tp] = (uint16_t) ((hit0 ? PC_HIT0 : 0u) | (hit1 ? PC_HIT1 : 0u) | (black0 ? PC_BLACK0 : 0u) | (black1 ? PC_BLACK1 : 0u) | (rank0 << 4) | (rank1 << 10));
+	if(lane == 0) p.ixh[chunk] = make_uint2(rec_base, n0h);
 	add_counters(p, cn, chunk, lane);
 }
 
@@ -214,21 +201,29 @@ SKR_DEV Activated activate_record(const SceneView &sv, const RenderParams &p, bo
 	if(act)
 	{
 		typedef float v4f __attribute__((ext_vector_type(4)));
-		const v4f *rv = reinterpret_cast<const v4f *>(p.rc + (size_t) rec * 2);
-		const v4f n0 = __builtin_nontemporal_load(&rv[0]), n1 = __builtin_nontemporal_load(&rv[1]); // streamed once
-		const f3 d = mk3(n0.x, n0.y, n0.z);
-		const float b = n0.w, D = n1.x;
-		a.r1 = n1.y;
-		const uint32_t parent = __float_as_uint(n1.z), sc = __float_as_uint(n1.w);
+		const v4f n0 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p.rc + rec)); // streamed once
+		const uint32_t parent = __float_as_uint(n0.x), sc = __float_as_uint(n0.y);
+		a.r1 = n0.z;
 		a.sph = sc & 0xffffu;
 		a.child = sc >> 16;
 		const float4 *row = p.nd_src + (size_t) parent * p.nd_src_stride;
-		const float4 p0 = row[0], p2 = row[2];
-		const f3 co0 = mk3(p0.x, p0.y, p0.z);
+		const float4 p0 = row[0], p1 = row[1], p2 = row[2];
+		const f3 co0 = mk3(p0.x, p0.y, p0.z), N0 = mk3(p0.w, p1.x, p1.y);
 		a.pixel = __float_as_uint(p2.y);
 		const uint32_t pnode = p.nd_src_level0 ? 0u : __float_as_uint(p2.z);
 		a.node_id = pnode * (uint32_t) p.num_path_traces + a.child + 1u; // DESIGN.md "RNG": child c of node n
-		const float two_a = 2 * dot3(d, d);
+		// The ray that found this hit, formed again from its two draws exactly as the trace kernel formed it (raytrace.h:119-125:
+		// same operations on the same values, so the same direction), and utils.h:115-118 for the sphere it hit: 16 bytes per
+		// record instead of 32
+		f3 nt0, nb0;
+		tangent_basis(N0, nt0, nb0);
+		const f3 d = gi_direction(a.r1, n0.w, N0, nt0, nb0);
+		const float4 g = sv.geom[a.sph];
+		const f3 ec = co0 - ld3(g);
+		const float aa = dot3(d, d);
+		const float b = 2 * dot3(d, ec);
+		const float D = b * b - (4 * aa) * (dot3(ec, ec) - g.w);
+		const float two_a = 2 * aa;
 		const float t = near_root_exact(two_a, b, D);
 		const f3 P = co0 + d * t;
 		a.N = normalize3(P - ld3(sv.geom[a.sph]));
@@ -275,7 +270,7 @@ struct Ring {
 	int head, count; // wave-uniform
 };
 
-SKR_DEV void ring_push(Ring &q, bool pred, f3 d, float b, float D, uint32_t ids, float r1)
+SKR_DEV void ring_push(Ring &q, bool pred, f3 d, uint32_t ids, float r1)
 {
 	const unsigned long long m = __ballot(pred);
 	if(pred)
@@ -286,10 +281,8 @@ SKR_DEV void ring_push(Ring &q, bool pred, f3 d, float b, float D, uint32_t ids,
 		r[0 * NQ_CAP] = d.x;
 		r[1 * NQ_CAP] = d.y;
 		r[2 * NQ_CAP] = d.z;
-		r[3 * NQ_CAP] = b;
-		r[4 * NQ_CAP] = D;
-		r[5 * NQ_CAP] = __uint_as_float(ids);
-		r[6 * NQ_CAP] = r1;
+		r[3 * NQ_CAP] = __uint_as_float(ids);
+		r[4 * NQ_CAP] = r1;
 	}
 	q.count = uni(q.count + (int) __popcll(m));
 }
@@ -307,14 +300,20 @@ SKR_DEV void leaf_batch(const SceneView &sv, const RenderParams &p, Ring &q, flo
 	e -= (e >= NQ_CAP) ? NQ_CAP : 0;
 	const float *r = q.base + e;
 	const f3 d = mk3(r[0 * NQ_CAP], r[1 * NQ_CAP], r[2 * NQ_CAP]);
-	const float b = r[3 * NQ_CAP], D = r[4 * NQ_CAP], r1 = r[6 * NQ_CAP];
-	const uint32_t ids = __float_as_uint(r[5 * NQ_CAP]);
+	const float r1 = r[4 * NQ_CAP];
+	const uint32_t ids = __float_as_uint(r[3 * NQ_CAP]);
 	const int kl = (int) ((ids >> 16) & 63u);
 	const f3 co_k = shfl3(co, act ? kl : 0);
 	if(act)
 	{
 		const int sph = (int) (ids & 0xffffu);
-		const float two_a = 2 * dot3(d, d);
+		// utils.h:115-118 for the winning sphere, as the trace formed them (same operations on the same values): b, D
+		const float4 g = sv.geom[sph];
+		const f3 ec = co_k - ld3(g);
+		const float a = dot3(d, d);
+		const float b = 2 * dot3(d, ec);
+		const float D = b * b - (4 * a) * (dot3(ec, ec) - g.w);
+		const float two_a = 2 * a;
 		const float t = near_root_exact(two_a, b, D);
 		const f3 P = co_k + d * t;
 		const f3 Nn = normalize3(P - ld3(sv.geom[sph]));
@@ -323,7 +322,7 @@ SKR_DEV void leaf_batch(const SceneView &sv, const RenderParams &p, Ring &q, flo
 		const f3 total = mk3(0, 0, 0) / (float) p.num_path_traces;
 		const f3 colour = (direct / (float) 3.14159265358979323846 + total * 2.0f) * ld3(sv.kd[sph]);
 		const f3 c = (colour * r1) / (float) (1 / 3.14159265358979323846);
-		float *s = slots + (int) ((ids >> 23) & (NWIN - 1)) * WIN_FLOATS + (int) ((ids >> 22) & 1u) * 192 + kl;
+		float *s = slots + (int) ((ids >> 23) & (NWIN - 1)) * WIN_FLOATS + (int) ((ids >> 22) & 1u) * 192 + kl; // [round][child][component][lane]
 		s[0] = c.x;
 		s[64] = c.y;
 		s[128] = c.z;
@@ -365,9 +364,6 @@ extern "C" void skr_leaf2_times_read(unsigned long long *out)
 	(void) hipMemcpyFromSymbol(out, HIP_SYMBOL(skr_leaf2_times), sizeof(unsigned long long) * 6 * 4096);
 }
 #endif
-#ifndef SKR_LEAF2_PRIO
-#define SKR_LEAF2_PRIO 0 // A/B builds
-#endif
 #ifndef SKR_LEAF2_OCC
 #define SKR_LEAF2_OCC 4 // waves per SIMD the register allocation aims at (A/B builds)
 #endif
@@ -388,7 +384,9 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 	unsigned long long dead = 0; // regions this wave has seen exhausted
 	// FIRST: the level-0 nodes form virtual regions — unit u of the node array belongs to region u mod 64
 	const uint32_t n_first = FIRST ? *p.nd_count : 0u;
-	const uint32_t units_first = (n_first + 63u) >> 6;
+	const uint32_t US = 64u; // records per unit, one lane each
+	const int pl = lane, cs = 64, R = PP;
+	const uint32_t units_first = (n_first + US - 1u) / US;
 	Counters cn{0, 0, 0};
 	STAMP_DECL; // (diagnostic builds: 0 pull, 1 activation, 2 trace, 3 leaf shading, 4 pushes + window sums, 5 unit end)
 #if defined(SKR_TIMELINE) && SKR_TIMELINE
@@ -398,7 +396,7 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 #endif
 	for(;;)
 	{
-		uint32_t first = 0, step = 1;
+		uint32_t first = 0;
 		int m = 0;
 		bool got = false;
 		for(;;)
@@ -411,28 +409,19 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 				const uint32_t u = k * SKR_P1_REGIONS + region;
 				if(u < units_first)
 				{
-					first = u * 64u;
-					m = (int) (n_first - first < 64u ? n_first - first : 64u);
+					first = u * US;
+					m = (int) (n_first - first < US ? n_first - first : US);
 					got = true;
 				}
 			}
 			else
 			{
 				const uint32_t cnt = *lc_count(p.rc_ctr, region);
-				const uint32_t units = (cnt + 63u) >> 6;
+				const uint32_t units = (cnt + US - 1u) / US;
 				if(k < units)
 				{
-					if(p.unit_strided)
-					{ // records k, k + units, k + 2 units, ...: a unit mixes hits from all over the region (equal unit costs)
-						first = k;
-						step = units;
-						m = (int) ((cnt - 1u - k) / units + 1u);
-					}
-					else
-					{
-						first = k * 64u;
-						m = (int) (cnt - first < 64u ? cnt - first : 64u);
-					}
+					first = k * US;
+					m = (int) (cnt - first < US ? cnt - first : US);
 					got = true;
 				}
 			}
@@ -456,12 +445,12 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 #endif
 
 		// ---- the unit's records become the nodes their lanes hold
-		const bool act = lane < m;
+		const bool act0 = lane < m; // the lane that shades record `lane` of the unit and writes its result
 		f3 co = mk3(0, 0, 1), Nn = mk3(0, 0, 1), direct1 = mk3(0, 0, 0);
 		uint32_t pixel = 0, node_id = 0, out_idx = 0; // out_idx: output pixel (FIRST) or this record's index
 		if(FIRST)
 		{
-			if(act)
+			if(act0)
 			{
 				const float4 *row = p.nd_src + (size_t) (first + (uint32_t) lane) * p.nd_src_stride;
 				const float4 a0 = row[0], a1 = row[1], a2 = row[2];
@@ -474,49 +463,41 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 		}
 		else
 		{
-			out_idx = region * p.rc_cap + first + (uint32_t) lane * step;
-			const Activated a = activate_record(sv, p, act, out_idx, cn);
+			out_idx = region * p.rc_cap + first + (uint32_t) lane;
+			const Activated a = activate_record(sv, p, act0, out_idx, cn);
 			co = a.co;
 			Nn = a.N;
 			direct1 = a.direct;
 			pixel = a.pixel;
 			node_id = a.node_id;
 		}
+		const bool act = act0;
 		f3 nt, nb;
 		tangent_basis(Nn, nt, nb);
-		// what is only needed when the unit is finished does not stay in registers: a level-0 node's row is read again,
-		// a record's direct light waits in the record's own result slot
-		if(!FIRST && act) store3(p.res_out + (size_t) out_idx * 3, direct1);
+		// (r1 and the sphere are only needed when the unit is finished: they are read again from the record / node row then)
 		STAMP(1);
 		// ---- rounds: children 2j, 2j+1 of every lane's node
 		f3 acc = mk3(0, 0, 0);
-		for(int j = 0; j < PP; j++)
+		for(int jj = 0; jj < R; jj++)
 		{
-			// The SIMD's arbiter serves its (persistent) waves by priority, then AGE: left alone, the oldest wave of a SIMD
-			// runs at full speed and the youngest on what is left, so that the waves that get nothing more from the queues
-			// leave early while the starved ones crawl through their last unit (per-wave timeline: last units done between
-			// 64 % and 100 % of the kernel's span).  The priority therefore follows the work a wave still has in hand.
-#if SKR_LEAF2_PRIO
-			{
-				const int left = 4 * (PP - j) / PP; // 4 .. 1
-				if(left >= 4) __builtin_amdgcn_s_setprio(3);
-				else if(left == 3) __builtin_amdgcn_s_setprio(2);
-				else if(left == 2) __builtin_amdgcn_s_setprio(1);
-				else __builtin_amdgcn_s_setprio(0);
+			const int j = jj;                         // this lane's sibling pair: children 2j, 2j + 1
+			const bool second = 2 * j + 1 < N;        // (wave-uniform)
+			float *wrow = slots + (jj & (NWIN - 1)) * WIN_FLOATS + pl; // the round's window: [child][component][64 lanes]
+			if(jj >= NWIN)
+			{ // the window is reused: add round jj - NWIN (its hits were shaded at the end of the previous round), child order
+				wave_lds_fence();
+				for(int c = 0; c < 2; c++) acc = acc + mk3(wrow[(3 * c) * cs], wrow[(3 * c + 1) * cs], wrow[(3 * c + 2) * cs]); // (rounds before the last have both children)
+				wave_lds_fence();
 			}
-#endif
-			const bool second = 2 * j + 1 < N; // (wave-uniform)
-			float *win = slots + (j & (NWIN - 1)) * WIN_FLOATS + lane;
-			if(j >= NWIN)
-			{ // the window is reused: add round j - NWIN (its hits were shaded at the end of the previous round)
-				wave_lds_fence();
-				acc = acc + mk3(win[0], win[64], win[128]);
-				acc = acc + mk3(win[192], win[256], win[320]); // (rounds before the last always have both children)
-				wave_lds_fence();
+			float *win = wrow;
+			if(q.count > NQ_PRE)
+			{ // room for the 128 hits this round can add (nothing but the nodes themselves is live here)
+				leaf_batch(sv, p, q, slots, co, lane, q.count < 64 ? q.count : 64, cn);
+				STAMP(3);
 			}
 			bool hit0 = false, hit1 = false;
 			f3 d0 = mk3(0, 0, 1), d1 = mk3(0, 0, 1);
-			float b0 = 0, D0 = 0, b1 = 0, D1 = 0, q1a = 0, q1b = 0;
+			float q1a = 0, q1b = 0;
 			int s0b = 0, s1b = 0;
 			if(act)
 			{
@@ -537,11 +518,9 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 				{ // raytrace.h:189-192 / :221-224, then :130: total += (r1 * colour) / pdf
 					const f3 c = ((black ? mk3(0, 0, 0) : p.background) * q1a) / pdf;
 					win[0] = c.x;
-					win[64] = c.y;
-					win[128] = c.z;
+					win[cs] = c.y;
+					win[2 * cs] = c.z;
 				}
-				b0 = s0.b;
-				D0 = s0.D;
 				s0b = s0.best;
 				if(second)
 				{
@@ -549,39 +528,29 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 					if(!hit1)
 					{
 						const f3 c = ((black ? mk3(0, 0, 0) : p.background) * q1b) / pdf;
-						win[192] = c.x;
-						win[256] = c.y;
-						win[320] = c.z;
+						win[3 * cs] = c.x;
+						win[4 * cs] = c.y;
+						win[5 * cs] = c.z;
 					}
-					b1 = s1.b;
-					D1 = s1.D;
 					s1b = s1.best;
 				}
 			}
 			STAMP(2);
-			const bool last = j + 1 == PP;
-			const uint32_t idj = ((uint32_t) lane << 16) | ((uint32_t) j << 23);
-			// the even children's hits, then the odd ones: never more than 63 + 64 queued, so a batch is shaded in between
-			// when both would not fit (rare: a round adds ~40 hits; the odd children's data then crosses that call)
-			ring_push(q, hit0, d0, b0, D0, (uint32_t) (s0b & 0xffff) | idj, q1a);
-			if(q.count + (int) __popcll(__ballot(hit1)) > NQ_CAP)
-			{
-				STAMP(4);
-				leaf_batch(sv, p, q, slots, co, lane, 64, cn);
-				STAMP(3);
-			}
-			ring_push(q, hit1, d1, b1, D1, (uint32_t) (s1b & 0xffff) | idj | (1u << 22), q1b);
+			const bool last = jj + 1 == R;
+			const uint32_t idj = ((uint32_t) lane << 16) | ((uint32_t) jj << 23);
+			ring_push(q, hit0, d0, (uint32_t) (s0b & 0xffff) | idj, q1a);
+			ring_push(q, hit1, d1, (uint32_t) (s1b & 0xffff) | idj | (1u << 22), q1b);
 			for(;;)
 			{
 				bool go = q.count >= 64;
 				if(!go && q.count > 0)
 				{ // after the round: everything, if it was the last one; otherwise the hits of the round whose window the NEXT round reuses
 					go = last;
-					if(!go && j + 1 >= NWIN)
+					if(!go && jj + 1 >= NWIN)
 					{
 						wave_lds_fence();
-						const uint32_t head_ids = (uint32_t) uni((int) __float_as_uint(q.base[5 * NQ_CAP + q.head]));
-						go = (int) (head_ids >> 23) <= j + 1 - NWIN;
+						const uint32_t head_ids = (uint32_t) uni((int) __float_as_uint(q.base[3 * NQ_CAP + q.head]));
+						go = (int) (head_ids >> 23) <= jj + 1 - NWIN;
 					}
 				}
 				if(!go) break;
@@ -593,14 +562,14 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 		}
 		// ---- the rounds still in their windows, in order
 		wave_lds_fence();
-		for(int jr = (PP > NWIN ? PP - NWIN : 0); jr < PP; jr++)
+		for(int jr = (R > NWIN ? R - NWIN : 0); jr < R; jr++)
 		{
-			const float *win = slots + (jr & (NWIN - 1)) * WIN_FLOATS + lane;
-			acc = acc + mk3(win[0], win[64], win[128]);
-			if(2 * jr + 1 < N) acc = acc + mk3(win[192], win[256], win[320]);
+			const float *wrow = slots + (jr & (NWIN - 1)) * WIN_FLOATS + pl;
+			for(int c = 0; c < 2; c++)
+				if(2 * jr + c < N) acc = acc + mk3(wrow[(3 * c) * cs], wrow[(3 * c + 1) * cs], wrow[(3 * c + 2) * cs]);
 		}
 		wave_lds_fence();
-		if(act)
+		if(act0)
 		{ // raytrace.h:133 + :213
 			f3 direct;
 			uint32_t sph;
@@ -608,17 +577,16 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 			if(FIRST)
 			{
 				const float4 *row = p.nd_src + (size_t) (first + (uint32_t) lane) * p.nd_src_stride;
-				const float4 a1 = row[1], a2 = row[2];
-				direct = mk3(a1.z, a1.w, a2.x);
+				const float4 a2 = row[2];
+				direct = direct1;
 				sph = __float_as_uint(a2.w);
 			}
 			else
 			{
-				const float *d3 = p.res_out + (size_t) out_idx * 3;
-				direct = mk3(d3[0], d3[1], d3[2]);
-				const float4 r1row = p.rc[(size_t) out_idx * 2 + 1];
-				r1 = r1row.y;
-				sph = __float_as_uint(r1row.w) & 0xffffu;
+				direct = direct1;
+				const float4 r1row = p.rc[out_idx];
+				r1 = r1row.z;
+				sph = __float_as_uint(r1row.y) & 0xffffu;
 			}
 			const f3 total = acc / (float) N;
 			const f3 colour = (direct / (float) 3.14159265358979323846 + total * 2.0f) * ld3(sv.kd[sph]);
@@ -658,43 +626,64 @@ __global__ __launch_bounds__(256) void skr_finalize_kernel2(const RenderParams p
 	const uint32_t node = (uint32_t) blockIdx.x * 256u + threadIdx.x;
 	if((uint32_t) blockIdx.x * 256u >= n) return;
 	if(node >= n) return;
-	const int N = p.num_path_traces;
+	const int N = p.num_path_traces, PP = (N + 1) >> 1;
 	const float pdf = (float) (1 / 3.14159265358979323846);
-	const uint32_t *w = p.ix + (size_t) node * p.ix_stride; // ix_stride is a multiple of 4 words: the 16-byte loads stay inside the row
+	const float4 *row = p.nd_src + (size_t) node * p.nd_src_stride;
+	const float4 a1 = row[1], a2 = row[2];
+	const uint32_t pixel = __float_as_uint(a2.y), node_id = p.nd_src_level0 ? 0u : __float_as_uint(a2.z);
 	f3 total = mk3(0, 0, 0);
-	for(int c0 = 0; c0 < N; c0 += 8)
-	{ // 8 children per trip: their words in two 16-byte loads, every gather issued before the first add
-		const uint4 wa = *reinterpret_cast<const uint4 *>(w + c0);
-		uint4 wb = make_uint4(IDX_BLACK, IDX_BLACK, IDX_BLACK, IDX_BLACK);
-		if(c0 + 4 < (int) p.ix_stride) wb = *reinterpret_cast<const uint4 *>(w + c0 + 4);
-		const uint32_t ww[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+	for(int j0 = 0; j0 < PP; j0 += 4)
+	{ // 4 sibling pairs (8 children) per trip: codes, headers and every gather issued before the first add
+		uint32_t code[4], rec[8];
 		f3 v[8];
+#pragma unroll
+		for(int k = 0; k < 4; k++)
+		{
+			const uint64_t tp = (uint64_t) node * (uint32_t) PP + (uint32_t) (j0 + k);
+			code[k] = 0;
+			rec[2 * k] = rec[2 * k + 1] = 0;
+			if(j0 + k < PP)
+			{
+				code[k] = p.ix16[tp];
+				const uint2 h = p.ixh[tp >> 6];
+				rec[2 * k] = h.x + ((code[k] >> 4) & 63u);
+				rec[2 * k + 1] = h.x + h.y + ((code[k] >> 10) & 63u);
+			}
+		}
 #pragma unroll
 		for(int k = 0; k < 8; k++)
 		{
 			v[k] = mk3(0, 0, 0);
-			if(c0 + k < N && (ww[k] & IDX_HIT))
+			if(code[k >> 1] & ((k & 1) ? PC_HIT1 : PC_HIT0))
 			{
-				const float *r = p.res_in + (size_t) (ww[k] & ~IDX_HIT) * 3;
+				const float *r = p.res_in + (size_t) rec[k] * 3;
 				v[k] = mk3(r[0], r[1], r[2]);
 			}
 		}
 #pragma unroll
-		for(int k = 0; k < 8; k++)
+		for(int k = 0; k < 4; k++)
 		{
-			if(c0 + k < N)
+			if(j0 + k < PP)
 			{
-				f3 term = v[k];
-				if(!(ww[k] & IDX_HIT))
-				{ // raytrace.h:189-192 / :221-224, then :130: (r1 * colour) / pdf; a triangle's (0 * r1) / pdf is +0
-					term = (ww[k] == IDX_BLACK) ? mk3(0, 0, 0) : (p.background * __uint_as_float(ww[k])) / pdf;
+				uint32_t rnd[4]; // the draws the trace kernel made for this pair: r1 of children 2j, 2j+1 (DESIGN.md "RNG")
+				philox4x32_10(pixel, p.aa_index, node_id, (uint32_t) (j0 + k), p.seed_lo, p.seed_hi, rnd);
+#pragma unroll
+				for(int c = 0; c < 2; c++)
+				{
+					if(2 * (j0 + k) + c < N)
+					{
+						f3 term = v[2 * k + c];
+						if(!(code[k] & (c ? PC_HIT1 : PC_HIT0)))
+						{ // raytrace.h:189-192 / :221-224, then :130: (r1 * colour) / pdf; a triangle's (0 * r1) / pdf is +0
+							const float r1 = u31_to_unit(rnd[2 * c]);
+							term = (code[k] & (c ? PC_BLACK1 : PC_BLACK0)) ? mk3(0, 0, 0) : (p.background * r1) / pdf;
+						}
+						total = total + term;
+					}
 				}
-				total = total + term;
 			}
 		}
 	}
-	const float4 *row = p.nd_src + (size_t) node * p.nd_src_stride;
-	const float4 a1 = row[1], a2 = row[2];
 	const f3 direct = mk3(a1.z, a1.w, a2.x);
 	const uint32_t sph = __float_as_uint(a2.w);
 	total = total / (float) N;
@@ -718,10 +707,9 @@ struct NodePlan {
 	int levels = 0;          // node / record levels 0 .. max_depth - 2
 	uint32_t band_nblk = 0;  // 16x16 pixel blocks per band
 	uint32_t stride0 = 3;    // float4 per level-0 node
-	uint32_t ix_stride = 0;
 	uint64_t nodes_max[SKR_NODE_LEVELS_MAX] = {};
 	uint32_t cap[SKR_NODE_LEVELS_MAX] = {};
-	size_t off_nodes[SKR_NODE_LEVELS_MAX] = {}, off_recs[SKR_NODE_LEVELS_MAX] = {}, off_res[SKR_NODE_LEVELS_MAX] = {}, off_ix[SKR_NODE_LEVELS_MAX] = {};
+	size_t off_nodes[SKR_NODE_LEVELS_MAX] = {}, off_recs[SKR_NODE_LEVELS_MAX] = {}, off_res[SKR_NODE_LEVELS_MAX] = {}, off_ix[SKR_NODE_LEVELS_MAX] = {}, off_ixh[SKR_NODE_LEVELS_MAX] = {};
 	size_t off_ctr = 0, ctr_bytes = 0, off_stash = 0, total = 0, banded = 0;
 };
 static uint32_t *lc_prefix_host(uint32_t *ctr) { return ctr + SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS + 1u) + 64; } // the level's record count (skr_prefix_kernel)
@@ -735,7 +723,6 @@ static bool plan_for(const RenderParams &p, uint32_t nblk, NodePlan &pl)
 	if(pl.levels < 1 || pl.levels > SKR_NODE_LEVELS_MAX) return false;
 	pl.band_nblk = nblk;
 	pl.stride0 = p.max_depth <= 3 ? 3u : 4u;
-	pl.ix_stride = (uint32_t) ((2 * PP + 3) & ~3ull);
 	pl.nodes_max[0] = (uint64_t) nblk * 256u;
 	pl.cap[0] = 0;
 	for(int L = 1; L < pl.levels; L++)
@@ -757,11 +744,15 @@ static bool plan_for(const RenderParams &p, uint32_t nblk, NodePlan &pl)
 		if(L == 0) pl.off_nodes[L] = take(n * pl.stride0 * 16);
 		else
 		{
-			pl.off_recs[L] = take(n * 32);
+			pl.off_recs[L] = take(n * 16);
 			pl.off_res[L] = take(n * 12 + 16);
 			if(L < pl.levels - 1) pl.off_nodes[L] = take(n * 64);
 		}
-		if(L < pl.levels - 1) pl.off_ix[L] = take(n * pl.ix_stride * 4 + 32);
+		if(L < pl.levels - 1)
+		{ // the children of level L: a 16-bit code per sibling pair, an 8-byte header per trace wave (64 pairs)
+			pl.off_ix[L] = take(n * PP * 2 + 64);
+			pl.off_ixh[L] = take((n * PP + 63) / 64 * 8 + 64);
+		}
 	}
 	pl.total = off;
 	pl.banded = off - (pl.off_nodes[0]); // what grows with the band; counters and the leaf kernel's stash are fixed
@@ -858,10 +849,8 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 	const uint32_t blocks_x = (uint32_t) (p.width + 15) / 16, blocks = blocks_x * ((p.out_rows + 15) / 16);
 	p.node_layout = 1;
 	p.blocks_x = blocks_x;
-	p.ix_stride = pl.ix_stride;
 	p.stash = reinterpret_cast<float *>(base + pl.off_stash);
 	p.qctr = ctr0; // [0]: the primary kernel counts its level-0 nodes here
-	p.unit_strided = (uint32_t) p.sw.unit_strided;
 	hipError_t e = hipSuccess;
 	for(int s = 0; s < nsamp; s++)
 	{
@@ -899,7 +888,8 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 				p.rc = reinterpret_cast<float4 *>(base + pl.off_recs[L]);
 				p.rc_cap = pl.cap[L];
 				p.rc_ctr = lvl_ctr(L);
-				p.ix = reinterpret_cast<uint32_t *>(base + pl.off_ix[L - 1]);
+				p.ix16 = reinterpret_cast<uint16_t *>(base + pl.off_ix[L - 1]);
+				p.ixh = reinterpret_cast<uint2 *>(base + pl.off_ixh[L - 1]);
 				const unsigned grid_t = (unsigned) ((pl.nodes_max[L - 1] * (uint64_t) ((p.num_path_traces + 1) >> 1) + 255) / 256);
 				if(tris) hipLaunchKernelGGL(skr_trace_kernel<true>, dim3(grid_t), dim3(256), lds_scene, stream, p);
 				else hipLaunchKernelGGL(skr_trace_kernel<false>, dim3(grid_t), dim3(256), lds_scene, stream, p);
@@ -925,7 +915,8 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 				p.nd_src_stride = L == 0 ? pl.stride0 : 4u;
 				p.nd_src_level0 = L == 0;
 				p.nd_count = L == 0 ? ctr0 : lc_prefix_host(lvl_ctr(L));
-				p.ix = reinterpret_cast<uint32_t *>(base + pl.off_ix[L]);
+				p.ix16 = reinterpret_cast<uint16_t *>(base + pl.off_ix[L]);
+				p.ixh = reinterpret_cast<uint2 *>(base + pl.off_ixh[L]);
 				p.res_in = reinterpret_cast<const float *>(base + pl.off_res[L + 1]);
 				p.res_out = L == 0 ? nullptr : reinterpret_cast<float *>(base + pl.off_res[L]);
 				hipLaunchKernelGGL(skr_finalize_kernel2, dim3((unsigned) ((pl.nodes_max[L] + 255) / 256)), dim3(256), 0, stream, p);

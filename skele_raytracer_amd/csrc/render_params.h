@@ -29,7 +29,6 @@ struct SkrSwitches {
 	int32_t tile = 0;                 // SKR_TILE = 64 | 32 | 16: pixels per wave tile of the megakernel (0 = choose)
 	int32_t no_cones = 0, no_cull = 0; // SKR_NO_CONES, SKR_NO_CULL: triangle-walk culling off
 	int32_t budget_mb = 0;            // SKR_LEVELS_BUDGET_MB: scratch budget of the level pipelines (0 = default)
-	int32_t unit_strided = 0;         // SKR_UNIT_STRIDE
 };
 
 struct RenderParams {
@@ -77,17 +76,16 @@ struct RenderParams {
 	uint32_t nd_src_stride, nd_dst_stride; // float4 per node: 3 or 4
 	uint32_t nd_src_level0;   // nd_src holds the primary hits: node id 0, row 2.z = output pixel index
 	const uint32_t *nd_count; // number of nodes in nd_src
-	float4 *rc;               // hit records of the level being produced (trace) or consumed (activate, leaf): [d.xyz b] [D r1 parent sphere|child<<16]
+	float4 *rc;               // hit records of the level being produced (trace) or consumed (activate, leaf): [parent, sphere | child << 16, r1, r2]
 	uint32_t rc_cap;          // records per region (SKR_P1_REGIONS regions)
 	uint32_t *rc_ctr;         // that level's counters: [STRIDE r] records in region r, [STRIDE (64 + r)] units handed out, [STRIDE 128] exhausted mask, [STRIDE 129 ..] prefix sums
-	uint32_t *ix;             // one word per child of the nd_src nodes, [node][ix_stride]: r1 (miss), IDX_BLACK (triangle), IDX_HIT | record
-	uint32_t ix_stride;       // words per node: 2 ceil(N/2) rounded up to a multiple of 4
+	uint16_t *ix16;           // one code per sibling pair of the nd_src nodes, [node * PP + j]: hit / triangle flags of children 2j, 2j+1 and their ranks among the trace wave's hits
+	uint2 *ixh;               // per trace wave (64 pairs): {first record of its even children's hits, how many of those}; its odd children's hits follow
 	uint32_t band_blk0, band_nblk, blocks_x; // node_layout: skr_primary_kernel covers the 16x16 pixel blocks [band_blk0, band_blk0 + band_nblk) of the launch (row-major, blocks_x per row)
 	void *node_scratch;       // (host) the pipeline's one allocation
 	const float *res_in;      // (colour r1)/pdf of every child record (finalize)
 	float *res_out;           // the same for this level's records (leaf kernel; finalize of a level >= 1)
 	float *stash;             // per-wave scratch of the leaf kernel (64 lanes x 8 floats per resident wave)
-	uint32_t unit_strided;    // leaf units take every U-th record of their region instead of 64 consecutive ones
 	uint32_t trace_chunks_max; // (host) bound on the trace kernel's 64-pair chunks: sizes rc_cap
 };
 

