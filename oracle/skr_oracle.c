@@ -380,7 +380,8 @@ static v3 direct_illumination(ctx_t *cx, const sko_sphere *sp, v3 P, v3 N)
 	return total;
 }
 
-static v3 shade(ctx_t *cx, v3 o, v3 d, int depth, uint32_t node);
+static v3 shade_from(ctx_t *cx, v3 o, v3 d, int depth, uint32_t node, int from_triangle);
+static inline v3 shade(ctx_t *cx, v3 o, v3 d, int depth, uint32_t node) { return shade_from(cx, o, d, depth, node, -1); }
 
 /* raytrace.h:22-30 uniform_sample_hemi */
 static inline v3 sample_hemi(const ctx_t *cx, float r1, float r2)
@@ -395,8 +396,8 @@ static inline v3 sample_hemi(const ctx_t *cx, float r1, float r2)
 
 /* raytrace.h:107-136 montecarlo_global_illumination, including the basis mix
  * of :123-125 (perp_to_both.y/.z where perp_to_normal.y/.z belongs). */
-static v3 global_illumination(ctx_t *cx, v3 P, v3 N, int depth, uint32_t node)
-{
+static v3 global_illumination(ctx_t *cx, v3 P, v3 N, int depth, uint32_t node, int from_triangle)
+{ /* from_triangle: --shade-triangles only, the triangle these child rays start on (they do not test it); -1 otherwise */
 	const int n_rays = cx->op->num_path_traces;
 	v3 total = V(0, 0, 0);
 	v3 nt, nb;
@@ -418,7 +419,7 @@ static v3 global_illumination(ctx_t *cx, v3 P, v3 N, int depth, uint32_t node)
 			v3 w = V(s.x * nb.x + s.y * N.x + s.z * nt.x,
 					 s.x * nb.y + s.y * N.y + s.z * nb.y,
 					 s.x * nb.z + s.y * N.z + s.z * nb.z);
-			child = shade(cx, vadds(P, 0.00001f), w, depth - 1, node * (uint32_t) n_rays + (uint32_t) i + 1u);
+			child = shade_from(cx, vadds(P, 0.00001f), w, depth - 1, node * (uint32_t) n_rays + (uint32_t) i + 1u, from_triangle);
 		}
 		/* depth-1 <= 0: shade() returns (0,0,0) at once (raytrace.h:142-145); r1*0/pdf == 0 for any finite r1 */
 		total = vadd(total, vdivs(vscale(child, r1), pdf));
@@ -428,7 +429,7 @@ static v3 global_illumination(ctx_t *cx, v3 P, v3 N, int depth, uint32_t node)
 }
 
 /* raytrace.h:139-227 shade */
-static v3 shade(ctx_t *cx, v3 o, v3 d, int depth, uint32_t node)
+static v3 shade_from(ctx_t *cx, v3 o, v3 d, int depth, uint32_t node, int from_triangle)
 {
 	const sko_scene *sc = cx->sc;
 	if(depth <= 0) return V(0, 0, 0);
@@ -451,21 +452,40 @@ static v3 shade(ctx_t *cx, v3 o, v3 d, int depth, uint32_t node)
 			}
 		}
 	}
+	int hit_triangle = -1;
 	for(int i = 0; i < sc->n_triangles; i++)
 	{
 		float t;
 		cx->n_tri_tests++;
 		if(triangle_test(o, d, &sc->triangles[i], &t))
 		{
+			if(cx->op->shade_triangles && (!(t > 0.0f) || i == from_triangle)) continue; /* skr_oracle.h: the mode's own rules */
 			if(t < min_distance)
 			{
 				min_distance = t;
 				hit_a_sphere = 0;
 				hit_a_triangle = 1;
+				hit_triangle = i;
 			}
 		}
 	}
 	if(!hit_a_sphere && !hit_a_triangle) return sc->background;
+	if(hit_a_triangle && cx->op->shade_triangles)
+	{ /* skr_oracle.h sko_options.shade_triangles: no counterpart in the reference */
+		const sko_triangle *tr = &sc->triangles[hit_triangle];
+		const sko_sphere *mt = &sc->triangle_materials[hit_triangle];
+		v3 P = vadd(o, vscale(d, min_distance));
+		v3 N = vnormalize(vcross(vsub(tr->v1, tr->v0), vsub(tr->v2, tr->v0)));
+		if(vdot(N, d) > 0.0f) N = V(-N.x, -N.y, -N.z);
+		cx->n_hits++;
+		v3 direct = direct_illumination(cx, mt, P, N);
+		if(cx->op->monte_carlo)
+		{
+			v3 indirect = global_illumination(cx, P, N, depth, node, hit_triangle);
+			return vmul(vadd(vdivs(direct, (float) M_PI), vscale(indirect, 2.0f)), mt->diffuse);
+		}
+		return direct;
+	}
 	if(hit_a_sphere)
 	{
 		const sko_sphere *sp = &sc->spheres[hit_sphere];
@@ -477,7 +497,7 @@ static v3 shade(ctx_t *cx, v3 o, v3 d, int depth, uint32_t node)
 		v3 direct = direct_illumination(cx, sp, P, N);
 		if(cx->op->monte_carlo)
 		{
-			v3 indirect = global_illumination(cx, P, N, depth, node);
+			v3 indirect = global_illumination(cx, P, N, depth, node, -1);
 			/* raytrace.h:213 */
 			return vmul(vadd(vdivs(direct, (float) M_PI), vscale(indirect, 2.0f)), sp->diffuse);
 		}
@@ -659,8 +679,14 @@ int sko_scene_load_ex(const char *path, int strict, sko_scene *out)
 				out->n_bad_triangles++;
 				continue;
 			}
-			if(out->n_triangles == cap_t) { cap_t = cap_t ? cap_t * 2 : 1024; out->triangles = realloc(out->triangles, sizeof(sko_triangle) * cap_t); }
+			if(out->n_triangles == cap_t)
+			{
+				cap_t = cap_t ? cap_t * 2 : 1024;
+				out->triangles = realloc(out->triangles, sizeof(sko_triangle) * cap_t);
+				out->triangle_materials = realloc(out->triangle_materials, sizeof(sko_sphere) * cap_t);
+			}
 			sko_triangle tr = {verts[i0], verts[i1], verts[i2]};
+			out->triangle_materials[out->n_triangles] = mat; /* shapes.h:26: the Triangle keeps the current material */
 			out->triangles[out->n_triangles++] = tr;
 		}
 		else if(!strcmp(command, "camera"))
@@ -739,6 +765,7 @@ void sko_scene_free(sko_scene *s)
 {
 	free(s->spheres);
 	free(s->triangles);
+	free(s->triangle_materials);
 	free(s->point_lights);
 	free(s->directional_lights);
 	memset(s, 0, sizeof *s);

@@ -51,6 +51,9 @@ typedef struct {
 	/* --strict-scn only (sko_scene_load_ex): the directional lights scene.cpp:139-163 builds and forgets, pushed */
 	int n_directional_lights;
 	sko_directional_light *directional_lights;
+	/* --shade-triangles only: the material in force when each triangle line was read (shapes.h:26 keeps it in the Triangle;
+	 * raytrace.h:221-224 never looks at it).  center / radius of these entries are unused. */
+	sko_sphere *triangle_materials;
 } sko_scene;
 
 enum { SKO_RNG_GLIBC_REPLAY = 0, SKO_RNG_COUNTER = 1 };
@@ -70,6 +73,14 @@ typedef struct {
 	uint64_t seed;            /* srand((unsigned)seed) in replay mode; Philox key in counter mode */
 	int32_t y0, y1;           /* rows [y0,y1) to render (whole image: 0,height) */
 	int32_t threads;          /* OpenMP threads; replay mode with rand() in use forces 1 */
+	/* --shade-triangles (NO reference behaviour exists: raytrace.h:221-224 returns black).  The spec of this mode:
+	 * a triangle is hit where utils.h:181-213 accepts it (flipped u and |det| >= 1e-5 kept) with 0 < t < the closest sphere's t
+	 * — the t > 0 test utils.h:213 lacks; hits behind the origin are ignored instead of blackening —, except the triangle the ray
+	 * starts on (--gillum children of a triangle hit: P + 1e-5 may lie on either side of it); the smallest t wins, the lower file
+	 * index on a tie; it is shaded like a sphere hit — the triangle's material, the geometric normal
+	 * normalize(cross(v1-v0, v2-v0)) turned against the ray, shadow rays against spheres only (utils.h:42-76), --gillum children
+	 * from P + 1e-5 with the basis of utils.h:148-165. */
+	int32_t shade_triangles;
 } sko_options;
 
 /* stats[0]=radiance rays (shade() calls with depth>0), [1]=sphere hits shaded,
