@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SKR_ABI_VERSION 2
+#define SKR_ABI_VERSION 3 /* 3: skr_options grew by shade_triangles (48 bytes); 2: multi-GPU entry points, skr_scene_info.n_directional_lights */
 
 typedef enum {
 	SKR_OK = 0,
@@ -54,6 +54,15 @@ typedef struct {
 	int32_t max_depth;        /* --depth d > 0, default 3 (utils.h:33) */
 	int32_t use_shadows;      /* --shadow (main.cpp:375-378); absent == 0 */
 	uint64_t seed;            /* new: key of the counter RNG that replaces srand(time(0)) (main.cpp:400) */
+	int32_t shade_triangles;  /* new, default 0 (`raytracer --shade-triangles`).  0 = HEAD: a ray whose closest hit is a
+	                           * triangle returns black (raytrace.h:221-224).  1 = triangles are surfaces: among the triangles
+	                           * utils.h:181-213 accepts with t > 0 (the one the ray starts on excepted) the smallest t wins if it is
+	                           * strictly below the closest sphere's (equal t: lower index in the file); the hit is shaded as a
+	                           * sphere is (blinn_phong.h, raytrace.h:107-136,208-218) with the material in force on its
+	                           * `triangle` line and the geometric normal normalize(cross(v1-v0, v2-v0)) turned against the ray;
+	                           * shadow rays still test spheres only (utils.h:42-76); the child rays of a triangle hit start at
+	                           * P + 1e-5 like a sphere's (raytrace.h:128).  No counterpart in the reference, so no reference output
+	                           * pins it (tests/test_shade_triangles.py).  Lane-per-pixel kernel, --depth <= 6. */
 } skr_options;
 
 typedef struct {
@@ -91,7 +100,7 @@ int skr_scene_get_info(const skr_scene *scene, skr_scene_info *info);
  * (any pointer may be NULL).  Used by the loader parity tests. */
 int skr_scene_get_arrays(const skr_scene *scene, float *spheres, float *triangles, float *point_lights);
 /* The culling data the triangle walk of raytrace.h:171-186 runs on, as uploaded:
- * device_tris[n_triangles][12] = {v0, 0, v1-v0, 0, v2-v0, 0} in device (Morton) order; chunk_spheres[n_chunks][8]
+ * device_tris[n_triangles][12] = {v0, 0, v1-v0, file index (int32 bits), v2-v0, 0} in device (Morton) order; chunk_spheres[n_chunks][8]
  * = {centre, R^2, axis / kappa, R_tight^2} of every *chunk_size consecutive device triangles (R_tight applies to
  * rays with (d . axis / kappa)^2 >= d . d; axis = 0 and R_tight = R where there is none); above them a tree in
  * depth-first order, node_spheres[n_nodes][8] likewise and node_links[n_nodes][4] = {skip (index of the next node
@@ -101,6 +110,11 @@ int skr_scene_get_arrays(const skr_scene *scene, float *spheres, float *triangle
  * tests. */
 int skr_scene_get_culling(const skr_scene *scene, int32_t level, int32_t *chunk_size, int32_t *n_nodes, int32_t *n_chunks,
 						  float *device_tris, float *node_spheres, int32_t *node_links, float *chunk_spheres);
+
+/* Materials of the triangles of a scene built from arrays, materials[n_triangles][10] = ambient(3) diffuse(3) specular(3)
+ * phong power — what the `material` line in force gives a `triangle` line in a .scn file (scene.cpp:110-137; the reference
+ * keeps no material for a triangle, shapes.h:26).  Read by skr_options.shade_triangles only; default: material.h:9-17's. */
+int skr_scene_set_triangle_materials(skr_scene *scene, const float *materials);
 
 /* ---- options: replaces Options' in-class defaults (utils.h:28-33) ---- */
 void skr_options_default(skr_options *opt);

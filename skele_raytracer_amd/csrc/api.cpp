@@ -38,8 +38,8 @@ static thread_local const char *g_variant = "none";
 struct skr_renderer {
 	int device = 0;
 	skr_scene_info info{};
-	float4 *d_blob = nullptr; // one allocation: geom | amb | kd | ks | lights | tris
-	size_t off_amb = 0, off_kd = 0, off_ks = 0, off_lights = 0, off_tris = 0, off_chunks = 0;
+	float4 *d_blob = nullptr; // one allocation: geom | amb | kd | ks | lights | tris | chunk trees | triangle materials
+	size_t off_amb = 0, off_kd = 0, off_ks = 0, off_lights = 0, off_tris = 0, off_chunks = 0, off_tri_mats = 0;
 	int n_chunks = 0, chunk_size = 0, cones = 0;
 	size_t chunk_stride = 0;
 	unsigned long long *d_counters = nullptr;
@@ -126,7 +126,9 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	r->chunk_stride = scene->tri_chunk_stride;
 	r->cones = scene->tri_any_cone ? 1 : 0;
 	r->n_chunks = scene->info.n_triangles ? scene->tri_node_count : 0; // nodes of the chunk tree (scene_host.h)
-	const size_t total = 4 * ns + nl2 + nt3 + nch;
+	const size_t ntm = scene->tri_mats.size();
+	r->off_tri_mats = 4 * ns + nl2 + nt3 + nch;
+	const size_t total = 4 * ns + nl2 + nt3 + nch + ntm;
 	std::vector<skr_f4> blob(total > 0 ? total : 1);
 	if(ns)
 	{
@@ -138,6 +140,7 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	if(nl2) memcpy(&blob[r->off_lights], scene->lights.data(), nl2 * 16);
 	if(nt3) memcpy(&blob[r->off_tris], scene->tris.data(), nt3 * 16);
 	if(nch) memcpy(&blob[r->off_chunks], scene->tri_chunks.data(), nch * 16);
+	if(ntm) memcpy(&blob[r->off_tri_mats], scene->tri_mats.data(), ntm * 16);
 	hipError_t e = hipMalloc((void **) &r->d_blob, blob.size() * 16);
 	if(e == hipSuccess) e = hipMemcpy(r->d_blob, blob.data(), blob.size() * 16, hipMemcpyHostToDevice);
 	if(e == hipSuccess) e = hipMalloc((void **) &r->d_counters, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long) + (SKR_PULL_QUEUES + 2 + 2 * SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t));
@@ -266,7 +269,20 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.use_shadows = opt->use_shadows ? 1 : 0;
 	// shade() only recurses under --gillum and only below a sphere hit (raytrace.h:208-218), and with N = 0 there is no
 	// child to recurse into: every --depth is then the depth-1 image
-	if(!p.monte_carlo || p.n_spheres == 0 || p.num_path_traces == 0) p.max_depth = 1;
+	// (--shade-triangles: a triangle hit recurses too)
+	p.shade_triangles = (opt->shade_triangles && p.n_tris > 0) ? 1 : 0;
+	p.tri_mats = r->d_blob + r->off_tri_mats;
+	if(!p.monte_carlo || (p.n_spheres == 0 && !p.shade_triangles) || p.num_path_traces == 0) p.max_depth = 1;
+	if(p.shade_triangles)
+	{ // only the lane-per-pixel kernel shades triangles (include/skr.h skr_options.shade_triangles)
+		p.sw.pipeline = SKR_PIPE_MEGA;
+		p.sw.kernel_v1 = 1;
+		if(p.max_depth > 6)
+		{
+			skr_set_error("--shade-triangles renders --depth <= 6 (asked for %d)", p.max_depth);
+			return SKR_ERR_UNSUPPORTED;
+		}
+	}
 	if(p.max_depth > 1)
 	{ // tree node ids are 32-bit RNG counter words: need N^(depth-1) < 2^32
 		double nodes = 1;

@@ -116,6 +116,7 @@ int main(int argc, char *argv[])
 		if(!strcmp(argv[i], "--tile-rows") && has_next) tile_rows = (uint32_t) (atoi(argv[i + 1]) > 0 ? atoi(argv[i + 1]) : 8);
 		if(!strcmp(argv[i], "--quiet")) quiet = true;
 		if(!strcmp(argv[i], "--strict-scn")) strict_scn = true;
+		if(!strcmp(argv[i], "--shade-triangles")) option.shade_triangles = 1; // new: triangles as surfaces (include/skr.h skr_options)
 	}
 	if(!path)
 	{

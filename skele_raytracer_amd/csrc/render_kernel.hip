@@ -59,11 +59,144 @@ SKR_DEV f3 shade(const SceneView &sv, const RenderParams &p, f3 o, f3 d, uint32_
 	}
 }
 
+// ---- --shade-triangles (the rules: include/skr.h skr_options.shade_triangles) ----
+// HEAD turns every accepted triangle into a black sample (raytrace.h:221-224).  In this mode a triangle is a surface:
+// among the triangles utils.h:181-213 accepts with 0 < t (the triangle the ray starts on excepted) the one with the
+// smallest t wins if that t is strictly below the closest sphere's; equal t: the lower index in the file.  It is then
+// shaded exactly as a sphere is (blinn_phong.h, raytrace.h:107-136,208-218) with the material in force on its
+// `triangle` line and the geometric normal normalize(cross(v1 - v0, v2 - v0)), turned against the ray.
+
+struct TriBest {
+	float t;  // smallest accepted distance so far (starts at the closest sphere's)
+	int file; // index of that triangle in the scene file, -1 = the sphere still wins
+	int slot; // its position in tris[]
+};
+
+SKR_DEV void tri_consider(const RayConst &r, bool mine, f3 v0, float4 n1, float4 n2, int slot, int from_tri, TriBest &b)
+{
+	float t;
+	if(mine && triangle_hit(r.o, r.d, v0, ld3(n1), ld3(n2), t) && t > 0.0f)
+	{
+		const int file = __float_as_int(n1.w);
+		if(file != from_tri && (t < b.t || (t == b.t && b.file >= 0 && file < b.file)))
+		{
+			b.t = t;
+			b.file = file;
+			b.slot = slot;
+		}
+	}
+}
+
+// The walk of shade_common.h tree_walk() without its early-outs: every chunk whose conservative sphere this lane's
+// line touches is tested to the end (the spheres bound the accept test itself, whatever t comes out).
+template <bool CONES>
+SKR_DEV void tree_walk_closest(const SceneView &sv, const RayConst &r, int from_tri, TriBest &b)
+{
+	const float dd = r.two_a * 0.5f; // dot(d, d)
+	int i = 0;
+	const float4 *chunk_ent = sv.chunks + 3 * (sv.nchunks + 1);
+	float4 A = sv.chunks[0], B = sv.chunks[1], lk = sv.chunks[2];
+	while(i < sv.nchunks)
+	{
+		const int i_out = __float_as_int(lk.x);
+		const float4 A_in = sv.chunks[3 * i + 3], B_in = sv.chunks[3 * i + 4], lk_in = sv.chunks[3 * i + 5];
+		const float4 A_out = sv.chunks[3 * i_out], B_out = sv.chunks[3 * i_out + 1], lk_out = sv.chunks[3 * i_out + 2];
+		const bool enter = __any(line_touches<CONES>(r, dd, A, B));
+		const int count = __float_as_int(lk.z);
+		if(enter && count > 0)
+		{
+			const int c0 = __float_as_int(lk.y), c1 = c0 + count;
+			for(int c = c0; c < c1; c++)
+			{
+				const bool mine = line_touches<CONES>(r, dd, chunk_ent[2 * c], chunk_ent[2 * c + 1]);
+				if(__any(mine))
+				{
+					const int i0 = c * sv.chunk, i1 = (i0 + sv.chunk < sv.nt) ? i0 + sv.chunk : sv.nt;
+					for(int k = i0; k < i1; k++) tri_consider(r, mine, ld3(sv.tris[3 * k]), sv.tris[3 * k + 1], sv.tris[3 * k + 2], k, from_tri, b);
+				}
+			}
+		}
+		i = enter ? i + 1 : i_out;
+		A = enter ? A_in : A_out;
+		B = enter ? B_in : B_out;
+		lk = enter ? lk_in : lk_out;
+	}
+}
+
+SKR_DEV void closest_triangle(const SceneView &sv, const RayConst &r, int from_tri, TriBest &b)
+{
+	if(sv.nchunks > 0)
+	{
+		if(sv.cones) tree_walk_closest<true>(sv, r, from_tri, b);
+		else tree_walk_closest<false>(sv, r, from_tri, b);
+		return;
+	}
+	for(int k = 0; k < sv.nt; k++) tri_consider(r, true, ld3(sv.tris[3 * k]), sv.tris[3 * k + 1], sv.tris[3 * k + 2], k, from_tri, b);
+}
+
+// shade() with shaded triangles; from_tri = file index of the triangle this ray starts on (-1: none)
+template <int LEVELS>
+SKR_DEV f3 shade_surfaces(const SceneView &sv, const RenderParams &p, f3 o, f3 d, uint32_t node, uint32_t pixel, uint32_t aa, int from_tri, Counters &cn)
+{
+	if constexpr(LEVELS <= 0) return mk3(0, 0, 0);
+	else
+	{
+		cn.rays++;
+		const RayConst r = make_ray(o, d);
+		float tmin;
+		const int sph = closest_sphere(sv, r, tmin);
+		TriBest b{tmin, -1, -1};
+		closest_triangle(sv, r, from_tri, b);
+		if(sph < 0 && b.slot < 0) return p.background;
+		cn.hits++;
+		const f3 P = o + d * b.t; // (== tmin for a sphere)
+		f3 N, kd, ks;
+		float4 ambp;
+		if(b.slot >= 0)
+		{
+			N = normalize3(cross3(ld3(sv.tris[3 * b.slot + 1]), ld3(sv.tris[3 * b.slot + 2])));
+			if(dot3(N, d) > 0.0f) N = mk3(-N.x, -N.y, -N.z);
+			ambp = p.tri_mats[3 * b.slot];
+			kd = ld3(p.tri_mats[3 * b.slot + 1]);
+			ks = ld3(p.tri_mats[3 * b.slot + 2]);
+		}
+		else
+		{
+			N = normalize3(P - ld3(sv.geom[sph]));
+			ambp = sv.amb[sph];
+			kd = ld3(sv.kd[sph]);
+			ks = ld3(sv.ks[sph]);
+		}
+		const f3 direct = direct_light_of(sv, p, kd, ks, ambp, P, N, cn);
+		if(!p.monte_carlo) return direct;
+
+		f3 total = mk3(0, 0, 0);
+		if constexpr(LEVELS > 1)
+		{
+			f3 nt, nb;
+			tangent_basis(N, nt, nb);
+			const float pdf = (float) (1 / 3.14159265358979323846);
+			const f3 co = add_scalar(P, 0.00001f);
+			uint32_t rnd[4];
+			for(int i = 0; i < p.num_path_traces; i++)
+			{
+				if((i & 1) == 0) philox4x32_10(pixel, aa, node, (uint32_t) i >> 1, p.seed_lo, p.seed_hi, rnd);
+				const float r1 = u31_to_unit(rnd[2 * (i & 1)]), r2 = u31_to_unit(rnd[2 * (i & 1) + 1]);
+				const f3 w = gi_direction(r1, r2, N, nt, nb);
+				const f3 child = shade_surfaces<LEVELS - 1>(sv, p, co, w, node * (uint32_t) p.num_path_traces + (uint32_t) i + 1u, pixel, aa, b.file, cn);
+				total = total + (child * r1) / pdf;
+			}
+		}
+		total = total / (float) p.num_path_traces;
+		return (direct / (float) 3.14159265358979323846 + total * 2.0f) * kd;
+	}
+}
+
 } // namespace
 
 // One workgroup = 4 waves = a 16x16 pixel tile; each wave owns an 8x8 sub-tile.
 // Dynamic LDS: scene SoA | 16 rows x 48 bytes of packed RGB for the tile.
-template <int DEPTH>
+template <int DEPTH, bool SURFACES>
 __global__ __launch_bounds__(256) void skr_render_kernel(const RenderParams p)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -110,7 +243,8 @@ __global__ __launch_bounds__(256) void skr_render_kernel(const RenderParams p)
 				const float u = ((2 * (((float) x + r) * p.inv_width) - 1) * p.angle) * p.aspect;
 				const float v = (1 - 2 * (((float) (int) y + r) * p.inv_height)) * p.angle;
 				const f3 dir = (p.cam_dir + p.cam_right * u) + p.cam_up * v;
-				px = px + shade<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, (uint32_t) s, cn);
+				if constexpr(SURFACES) px = px + shade_surfaces<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, (uint32_t) s, -1, cn);
+				else px = px + shade<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, (uint32_t) s, cn);
 			}
 			px = px / (float) ns2;
 		}
@@ -119,7 +253,8 @@ __global__ __launch_bounds__(256) void skr_render_kernel(const RenderParams p)
 			const float u = (float) (((2 * (((double) x + 0.5) * (double) p.inv_width) - 1) * (double) p.angle) * (double) p.aspect);
 			const float v = (float) ((1 - 2 * (((double) (int) y + 0.5) * (double) p.inv_height)) * (double) p.angle);
 			const f3 dir = (p.cam_dir + p.cam_right * u) + p.cam_up * v;
-			px = shade<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, 0u, cn);
+			if constexpr(SURFACES) px = shade_surfaces<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, 0u, -1, cn);
+			else px = shade<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, 0u, cn);
 		}
 		if(p.rgbf)
 		{
@@ -212,7 +347,8 @@ size_t skr_render_lds_bytes(const RenderParams &p)
 template <int D>
 static hipError_t launch_depth(const RenderParams &p, dim3 grid, size_t lds, hipStream_t stream)
 {
-	hipLaunchKernelGGL(skr_render_kernel<D>, grid, dim3(256), lds, stream, p);
+	if(p.shade_triangles) hipLaunchKernelGGL((skr_render_kernel<D, true>), grid, dim3(256), lds, stream, p);
+	else hipLaunchKernelGGL((skr_render_kernel<D, false>), grid, dim3(256), lds, stream, p);
 	return hipGetLastError();
 }
 
@@ -243,7 +379,7 @@ hipError_t skr_launch_render(const RenderParams &p, hipStream_t stream, const ch
 	}
 	const dim3 grid((p.width + 15) / 16, (p.out_rows + 15) / 16);
 	const size_t lds = skr_render_lds_bytes(p);
-	*variant = "lane_per_pixel_dfs_v1f";
+	*variant = p.shade_triangles ? "lane_per_pixel_surfaces_v1s" : "lane_per_pixel_dfs_v1f";
 	if(hook && hook->start) (void) hipEventRecord(hook->start, stream);
 	hipError_t e = hipErrorInvalidValue;
 	switch(p.max_depth)

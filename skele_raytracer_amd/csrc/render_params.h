@@ -87,6 +87,9 @@ struct RenderParams {
 	float *res_out;           // the same for this level's records (leaf kernel; finalize of a level >= 1)
 	float *stash;             // per-wave scratch of the leaf kernel (64 lanes x 8 floats per resident wave)
 	uint32_t trace_chunks_max; // (host) bound on the trace kernel's 64-pair chunks: sizes rc_cap
+	// --shade-triangles (lane-per-pixel kernel only): triangles are surfaces, not black holes
+	int32_t shade_triangles;
+	const float4 *tri_mats;   // 3 float4 per triangle, in tris[] order: [La*ka, power] [kd] [ks] (the rows sph_amb / sph_kd / sph_ks hold for a sphere)
 };
 
 // Optional timing of the dominant kernel of a launch (skr_renderer_kernel_ms): the launcher records the

@@ -128,10 +128,33 @@ void skr_scene::finalize()
 	{
 		const float *t = &raw_triangles[(size_t) order[i] * 9];
 		tris[3 * i] = {t[0], t[1], t[2], 0.0f};
-		tris[3 * i + 1] = {t[3] - t[0], t[4] - t[1], t[5] - t[2], 0.0f};
+		float file_index;
+		const int32_t fi = order[i];
+		memcpy(&file_index, &fi, 4);
+		tris[3 * i + 1] = {t[3] - t[0], t[4] - t[1], t[5] - t[2], file_index};
 		tris[3 * i + 2] = {t[6] - t[0], t[7] - t[1], t[8] - t[2], 0.0f};
 	}
+	tri_order = order;
+	build_triangle_materials();
 	build_triangle_chunks();
+}
+
+void skr_scene::build_triangle_materials()
+{
+	const int nt = info.n_triangles;
+	tri_mats.assign((size_t) nt * 3, skr_f4{0.0f, 0.0f, 0.0f, 0.0f});
+	for(int i = 0; i < nt; i++)
+	{
+		const Material dflt;
+		const size_t at = (size_t) tri_order[i] * 10;
+		const bool have = at + 10 <= raw_triangle_materials.size();
+		const float *m = have ? &raw_triangle_materials[at] : dflt.ambient;
+		const float power = have ? m[9] : dflt.power;
+		const float *kd = have ? m + 3 : dflt.diffuse, *ks = have ? m + 6 : dflt.specular;
+		tri_mats[3 * i] = {info.ambient[0] * m[0], info.ambient[1] * m[1], info.ambient[2] * m[2], power};
+		tri_mats[3 * i + 1] = {kd[0], kd[1], kd[2], 0.0f};
+		tri_mats[3 * i + 2] = {ks[0], ks[1], ks[2], 0.0f};
+	}
 }
 
 // Exact-preserving culling data for the triangle walk (DESIGN.md "Triangle chunks").
@@ -520,6 +543,11 @@ int skr_parse_scn(const std::string &path, bool echo, bool strict, skr_scene &sc
 				continue;
 			}
 			for(long i : idx) sc.raw_triangles.insert(sc.raw_triangles.end(), &verts[(size_t) i * 3], &verts[(size_t) i * 3] + 3);
+			{
+				const float rec[10] = {mat.ambient[0], mat.ambient[1], mat.ambient[2], mat.diffuse[0], mat.diffuse[1], mat.diffuse[2],
+									   mat.specular[0], mat.specular[1], mat.specular[2], mat.power};
+				sc.raw_triangle_materials.insert(sc.raw_triangle_materials.end(), rec, rec + 10);
+			}
 			info.n_triangles++;
 		}
 		else if(cmd == "camera")
@@ -671,6 +699,18 @@ int skr_scene_create_from_arrays(const float *spheres, int32_t n_spheres, const 
 	return SKR_OK;
 }
 
+int skr_scene_set_triangle_materials(skr_scene *scene, const float *materials)
+{
+	if(!scene || (scene->info.n_triangles && !materials))
+	{
+		skr_set_error("skr_scene_set_triangle_materials: bad argument");
+		return SKR_ERR_ARG;
+	}
+	scene->raw_triangle_materials.assign(materials, materials + (size_t) scene->info.n_triangles * 10);
+	scene->build_triangle_materials();
+	return SKR_OK;
+}
+
 void skr_scene_destroy(skr_scene *scene) { delete scene; }
 
 int skr_scene_get_info(const skr_scene *scene, skr_scene_info *info)
@@ -721,6 +761,7 @@ void skr_options_default(skr_options *opt)
 	opt->max_depth = 3;
 	opt->use_shadows = 0;
 	opt->seed = 1;
+	opt->shade_triangles = 0;
 }
 
 uint64_t skr_radiance_ray_count(const skr_options *opt)

@@ -20,6 +20,8 @@ struct skr_scene {
 	// raw values as parsed (skr_scene_get_arrays, loader parity tests)
 	std::vector<float> raw_spheres;      // [n][14] centre radius ambient diffuse specular power
 	std::vector<float> raw_triangles;    // [n][9]  v0 v1 v2
+	std::vector<float> raw_triangle_materials; // [n][10] ambient diffuse specular power: the material in force on each `triangle` line
+	                                     //         (read by --shade-triangles only; shorter than n = the default material, material.h:9-17)
 	std::vector<float> raw_point_lights; // [n][6]  position colour
 	std::vector<float> raw_directional_lights; // [n][6] direction colour — --strict-scn only (scene.cpp:139-163 drops them)
 	bool strict = false;                 // parsed with SKR_SCN_STRICT
@@ -31,7 +33,8 @@ struct skr_scene {
 	std::vector<skr_f4> sph_kd;   // material.diffuse
 	std::vector<skr_f4> sph_ks;   // material.specular
 	std::vector<skr_f4> lights;   // [2*i] position (.w = 0) or, behind the point lights, direction (.w = 1: --strict-scn), [2*i+1] colour
-	std::vector<skr_f4> tris;     // [3*i] v0, [3*i+1] v1-v0, [3*i+2] v2-v0 (utils.h:183-184 subtractions)
+	std::vector<skr_f4> tris;     // [3*i] v0, [3*i+1] v1-v0, [3*i+2] v2-v0 (utils.h:183-184 subtractions); [3*i+1].w = the triangle's index in the file (int bits)
+	std::vector<skr_f4> tri_mats; // [3*i] La*ka, power  [3*i+1] kd  [3*i+2] ks of the triangle stored at tris[3*i] (--shade-triangles)
 	// the culling data of the triangle walk: a tree, depth-first with skip links, three float4 per node — {centre, R^2}
 	// {axis / kappa, R_tight^2} {skip, first chunk, chunk count, height} (ints) — + one pad node, then two float4 per
 	// chunk of tri_chunk_size consecutive triangles — {centre, R^2} {axis / kappa, R_tight^2} — + one pad entry.
@@ -45,6 +48,8 @@ struct skr_scene {
 	int tri_node_count = 0;
 	bool tri_any_cone = false; // some chunk has a tight radius for non-grazing rays (scene_host.cpp)
 	void build_triangle_chunks();
+	std::vector<int> tri_order; // tris[3*i] holds triangle tri_order[i] of the file
+	void build_triangle_materials();
 	void build_triangle_chunk_level(double d_max, std::vector<skr_f4> &out);
 };
 

@@ -279,10 +279,9 @@ SKR_DEV LightTerm light_term(const SceneView &sv, int i, f3 P)
 
 // raytrace.h:36-44 = bp::ambient (blinn_phong.h:13) + diffuse (:47) + specular (:90).
 // The reference casts the same shadow ray in diffuse and again in specular; one cast serves both.
-SKR_DEV f3 direct_light(const SceneView &sv, const RenderParams &p, int sph, f3 P, f3 N, Counters &cn)
+// (kd, ks, ambp = {La * ka, power}: the material rows of the surface hit)
+SKR_DEV f3 direct_light_of(const SceneView &sv, const RenderParams &p, f3 kd, f3 ks, float4 ambp, f3 P, f3 N, Counters &cn)
 {
-	const f3 kd = ld3(sv.kd[sph]), ks = ld3(sv.ks[sph]);
-	const float4 ambp = sv.amb[sph];
 	f3 diffuse = mk3(0, 0, 0), specular = mk3(0, 0, 0);
 	const f3 view = normalize3(p.cam_pos - P); // always the camera (blinn_phong.h:93)
 	for(int i = 0; i < sv.nl; i += 2)
@@ -318,6 +317,11 @@ SKR_DEV f3 direct_light(const SceneView &sv, const RenderParams &p, int sph, f3 
 	total = total + diffuse;
 	total = total + specular;
 	return total;
+}
+
+SKR_DEV f3 direct_light(const SceneView &sv, const RenderParams &p, int sph, f3 P, f3 N, Counters &cn)
+{
+	return direct_light_of(sv, p, ld3(sv.kd[sph]), ld3(sv.ks[sph]), sv.amb[sph], P, N, cn);
 }
 
 // raytrace.h:22-30 + :117-125: hemisphere sample and the reference's basis mix

@@ -75,6 +75,8 @@ def _parse(argv):
             opt["shadow"] = True
         elif a == "--strict-scn":
             opt["strict_scn"] = True
+        elif a == "--shade-triangles":
+            opt["shade_triangles"] = True
         elif a == "--seed":
             opt["seed"] = value(i, _atoi, "seed takes an int")
         elif a == "--tile-rows":
@@ -139,7 +141,7 @@ def main(argv=None):
         if "depth" not in o["_given"] and info.max_depth_parsed > 0:
             o["depth"] = info.max_depth_parsed
     r = skr.Renderer(scene, local_rank)
-    kw = dict(fov=o["fov"], depth=o["depth"], shadow=o["shadow"], seed=o["seed"])
+    kw = dict(fov=o["fov"], depth=o["depth"], shadow=o["shadow"], seed=o["seed"], shade_triangles=bool(o.get("shade_triangles")))
     if o["gillum"] is not None:
         kw["gillum"] = o["gillum"]
     if o["jsample"] is not None:

@@ -87,9 +87,11 @@ def test_device_triangles_are_a_permutation_of_the_file_triangles(name):
     n = raw.shape[0]
     want = np.concatenate([raw[:, 0:3], raw[:, 3:6] - raw[:, 0:3], raw[:, 6:9] - raw[:, 0:3]], axis=1)  # utils.h:183-184
     got = tris[:, :, :3].reshape(n, 9)
-    assert np.all(tris[:, :, 3] == 0)
-    key = lambda a: a[np.lexsort(a.T[::-1])]
-    assert np.array_equal(key(want), key(got))
+    # row 1's .w carries the triangle's index in the file (--shade-triangles breaks ties by it): the permutation, exactly
+    order = tris[:, 1, 3].copy().view(np.int32)
+    assert np.all(tris[:, 0, 3] == 0) and np.all(tris[:, 2, 3] == 0)
+    assert np.array_equal(np.sort(order), np.arange(n))
+    assert np.array_equal(want[order], got)
     assert cs == (4 if sc.info.n_spheres == 0 else 16)
 
 
