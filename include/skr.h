@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SKR_ABI_VERSION 3 /* 3: skr_options grew by shade_triangles (48 bytes); 2: multi-GPU entry points, skr_scene_info.n_directional_lights */
+#define SKR_ABI_VERSION 3 /* 3: skr_options grew by shade_triangles and progressive_passes (48 bytes); 2: multi-GPU entry points, skr_scene_info.n_directional_lights */
 
 typedef enum {
 	SKR_OK = 0,
@@ -63,6 +63,10 @@ typedef struct {
 	                           * shadow rays still test spheres only (utils.h:42-76); the child rays of a triangle hit start at
 	                           * P + 1e-5 like a sphere's (raytrace.h:128).  No counterpart in the reference, so no reference output
 	                           * pins it (tests/test_shade_triangles.py).  Lane-per-pixel kernel, --depth <= 6. */
+	int32_t progressive_passes; /* new, default 1 (`raytracer --progressive K`, SURVEY.md 8f-4: what the SDL viewer of main.cpp:183-197 is
+	                           * for, headless).  K > 1: every render entry point traces K whole frames under the seeds seed, seed+1, ...,
+	                           * seed+K-1, sums them in binary32 in that order, divides by (float) K once and quantises the mean like
+	                           * a single frame (main.cpp:205).  K <= 1 is the single frame, bit for bit. */
 } skr_options;
 
 typedef struct {
@@ -149,6 +153,11 @@ uint32_t skr_tile_count(const skr_options *opt, uint32_t tile_rows, uint32_t fir
 /* Contiguous rows [y0, y1) (one tile of y1-y0 rows starting at y0). */
 int skr_render_rows(skr_renderer *r, const skr_options *opt, uint32_t y0, uint32_t y1, uint8_t *d_rgb, float *d_rgbf,
 					void *stream);
+/* The two steps of the progressive mean, for callers that want to look at it while it forms (`raytracer --progressive K
+ * --progressive-every M`): d_acc = d_frame (first != 0) or d_acc + d_frame over n_floats binary32 values; then
+ * d_rgbf = d_acc / (float) passes and d_rgb = its quantised bytes for a whole width x height frame.  DEVICE pointers. */
+int skr_accumulate(float *d_acc, const float *d_frame, uint64_t n_floats, int first, void *stream);
+int skr_resolve_accumulated(const float *d_acc, uint32_t passes, uint32_t width, uint32_t height, uint8_t *d_rgb, float *d_rgbf, void *stream);
 /* Work counters accumulated by the kernels since the last reset (synchronous):
  * out[0] radiance rays = shade() calls with depth > 0, out[1] sphere hits shaded,
  * out[2] shadow rays (one per light per hit; the reference casts each twice). */
@@ -173,6 +182,14 @@ int skr_renderer_last_parent_count(skr_renderer *r, uint32_t *n);
 int skr_renderer_last_level1_count(skr_renderer *r, uint32_t *n);
 /* Whole frame into HOST memory (W*H*3 bytes), synchronous; what the CLI uses. */
 int skr_render_frame_host(skr_renderer *r, const skr_options *opt, uint8_t *h_rgb, float *kernel_ms);
+/* The same with the float frame as a second output (h_rgb or h_rgbf may be NULL, not both) and — under
+ * opt->progressive_passes = K > 1 — a look at the mean while it forms: after every `every` passes and after the last one the
+ * mean so far is resolved into the host buffers and `progress(user, passes_done, K, h_rgb, h_rgbf)` is called (the place where
+ * the SDL viewer of main.cpp:183-197 blits; a non-zero return stops the render with that mean in the buffers).  every == 0 or
+ * progress == NULL: one call at the end / none.  The final buffers never depend on `every`.  kernel_ms: device time, summed. */
+typedef int (*skr_progress_fn)(void *user, uint32_t passes_done, uint32_t passes, const uint8_t *h_rgb, const float *h_rgbf);
+int skr_render_progressive_host(skr_renderer *r, const skr_options *opt, uint32_t every, uint8_t *h_rgb, float *h_rgbf,
+								skr_progress_fn progress, void *user, float *kernel_ms);
 
 /* ---- multi-GPU: the frame sharded over the GPUs of one node ----
  * Replaces the reference's only parallel entry, `generate_rays_parallel` (main.cpp:19-104: `#pragma omp parallel for`
@@ -212,6 +229,11 @@ int skr_shard_deinterleave_host(const uint8_t *gathered, uint8_t *frame, int32_t
 
 /* ---- image file: replaces the inline writer main.cpp:199-211 ---- */
 int skr_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb);
+/* Other outputs (new; `raytracer --format ppm|png|pfm`).  PNG: the same bytes as the PPM, 8-bit RGB (stored
+ * deflate blocks: no compressor is linked).  PFM: the unquantised float frame, "PF\nW H\n-1.0\n" + binary32 RGB, bottom row
+ * first; rgbf is top row first like every buffer of this interface. */
+int skr_write_png(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb);
+int skr_write_pfm(const char *path, uint32_t width, uint32_t height, const float *rgbf);
 
 /* ---- diagnostics ---- */
 const char *skr_last_error(void);      /* thread-local text of the last failure */

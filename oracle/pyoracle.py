@@ -152,6 +152,32 @@ def render(scene, width, height, *, fov=60.0, gillum=None, jsample=0, depth=3, s
     return rgb, rgbf, stats
 
 
+def quantise(img):
+    """main.cpp:205 on a float array: sko_quantise element by element (vectorised restatement of skr_oracle.c sko_quantise)."""
+    c = np.asarray(img, np.float32)
+    with np.errstate(invalid="ignore"):
+        m = np.where(c < np.float32(1.0), c, np.float32(1.0))  # std::min(1.0f, c): NaN -> 1
+        s = m * np.float32(255)
+        ok = s > np.float32(-2147483648.0)
+        return np.where(ok, np.where(ok, s, 0).astype(np.int64) & 0xff, 0).astype(np.uint8)
+
+
+def render_progressive(scene, width, height, passes, *, seed=1, **kw):
+    """--progressive K (no counterpart in the reference beyond its SDL viewer's purpose, main.cpp:183-197): K whole
+    frames under the seeds seed, seed+1, ..., summed in binary32 in that order, divided by (float) K once, quantised like a single
+    frame.  Returns (rgb, mean float image, summed stats, [mean after 1, 2, ... K passes])."""
+    if isinstance(scene, (str, os.PathLike)):
+        scene = OracleScene(scene, strict=kw.get("strict", False))
+    acc, stats, means = None, np.zeros(5, np.uint64), []
+    for k in range(passes):
+        _, f, st = render(scene, width, height, seed=(seed + k) & 0xFFFFFFFFFFFFFFFF, want_float=True, **{a: b for a, b in kw.items() if a != "want_float"})
+        acc = f.copy() if acc is None else acc + f
+        stats += st
+        with np.errstate(invalid="ignore", divide="ignore"):
+            means.append(acc / np.float32(k + 1))
+    return quantise(means[-1]), means[-1], stats, means
+
+
 def read_ppm(path):
     with open(path, "rb") as f:
         data = f.read()

@@ -12,7 +12,7 @@ There is no CPU fallback: every render entry point raises if libskr.so or a
 gfx950 device is missing.
 """
 from .binding import (Options, Renderer, Scene, SkrError, lib, lib_path, parse_scene, radiance_ray_count,
-                      write_ppm, EXPORTED_SYMBOLS)
+                      write_ppm, write_png, write_pfm, EXPORTED_SYMBOLS)
 
 __all__ = ["Options", "Renderer", "Scene", "SkrError", "lib", "lib_path", "parse_scene", "radiance_ray_count",
-           "write_ppm", "EXPORTED_SYMBOLS"]
+           "write_ppm", "write_png", "write_pfm", "EXPORTED_SYMBOLS"]

@@ -11,7 +11,7 @@ EXPORTED_SYMBOLS = [
     "skr_scene_create_from_scn", "skr_scene_create_from_scn_ex", "skr_scene_create_from_arrays", "skr_scene_set_triangle_materials", "skr_scene_destroy", "skr_scene_get_info",
     "skr_scene_get_arrays", "skr_scene_get_culling", "skr_options_default", "skr_radiance_ray_count", "skr_device_count",
     "skr_renderer_create", "skr_renderer_destroy", "skr_render_tiles", "skr_tile_count", "skr_render_rows",
-    "skr_renderer_read_counters", "skr_renderer_read_work", "skr_renderer_reload_switches", "skr_renderer_kernel_timing", "skr_renderer_kernel_ms", "skr_renderer_last_parent_count", "skr_renderer_last_level1_count", "skr_render_frame_host", "skr_write_ppm", "skr_last_error",
+    "skr_renderer_read_counters", "skr_renderer_read_work", "skr_renderer_reload_switches", "skr_renderer_kernel_timing", "skr_renderer_kernel_ms", "skr_renderer_last_parent_count", "skr_renderer_last_level1_count", "skr_render_frame_host", "skr_render_progressive_host", "skr_accumulate", "skr_resolve_accumulated", "skr_write_png", "skr_write_pfm", "skr_write_ppm", "skr_last_error",
     "skr_kernel_variant", "skr_debug_eval",
     "skr_rccl_available", "skr_multi_create", "skr_multi_destroy", "skr_multi_device_count", "skr_multi_renderer", "skr_multi_render_frame",
     "skr_multi_render_frame_host", "skr_comm_unique_id", "skr_comm_create", "skr_comm_destroy", "skr_comm_render_frame", "skr_comm_frame_to_host",
@@ -27,7 +27,11 @@ class COptions(C.Structure):
     # struct skr_options == reference struct Options (utils.h:26-34) + width/height/use_shadows
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fov", C.c_float), ("monte_carlo", C.c_int32),
                 ("num_path_traces", C.c_int32), ("grid_size", C.c_int32), ("max_depth", C.c_int32),
-                ("use_shadows", C.c_int32), ("seed", C.c_uint64), ("shade_triangles", C.c_int32)]
+                ("use_shadows", C.c_int32), ("seed", C.c_uint64), ("shade_triangles", C.c_int32), ("progressive_passes", C.c_int32)]
+
+
+# include/skr.h skr_progress_fn: (user, passes_done, passes, h_rgb, h_rgbf) -> non-zero stops the render
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p)
 
 
 class CSceneInfo(C.Structure):
@@ -91,6 +95,11 @@ def lib():
     L.skr_renderer_last_level1_count.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.skr_render_frame_host.argtypes = [vp, C.POINTER(COptions), vp, C.POINTER(C.c_float)]
     L.skr_write_ppm.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
+    L.skr_write_png.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
+    L.skr_write_pfm.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
+    L.skr_render_progressive_host.argtypes = [vp, C.POINTER(COptions), C.c_uint32, vp, vp, PROGRESS_FN, vp, C.POINTER(C.c_float)]
+    L.skr_accumulate.argtypes = [vp, vp, C.c_uint64, C.c_int, vp]
+    L.skr_resolve_accumulated.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.skr_last_error.restype = C.c_char_p
     L.skr_kernel_variant.restype = C.c_char_p
     L.skr_debug_eval.argtypes = [C.c_int, vp, vp, C.c_uint32, vp]
@@ -125,7 +134,7 @@ class Options:
     """Reference struct Options (utils.h:26-34) with the reference's defaults, plus the
     width/height/use_shadows main() folds in (main.cpp:393-396) and the RNG seed."""
 
-    def __init__(self, width=1920, height=1080, fov=60.0, gillum=None, jsample=0, depth=3, shadow=False, seed=1, shade_triangles=False):
+    def __init__(self, width=1920, height=1080, fov=60.0, gillum=None, jsample=0, depth=3, shadow=False, seed=1, shade_triangles=False, progressive=1):
         c = COptions()
         lib().skr_options_default(C.byref(c))
         c.width, c.height, c.fov = width, height, fov
@@ -133,6 +142,7 @@ class Options:
             c.monte_carlo, c.num_path_traces = 1, gillum
         c.grid_size, c.max_depth, c.use_shadows, c.seed = jsample, depth, int(bool(shadow)), seed
         c.shade_triangles = int(bool(shade_triangles))  # --shade-triangles (include/skr.h): triangles as surfaces, not black holes
+        c.progressive_passes = max(1, int(progressive))  # --progressive K: the mean of K frames under the seeds seed .. seed+K-1
         self.c = c
 
     @property
@@ -220,6 +230,20 @@ def write_ppm(path, rgb):
     _check(lib().skr_write_ppm(os.fsencode(path), w, h, rgb.ctypes.data), "skr_write_ppm")
 
 
+def write_png(path, rgb):
+    """The bytes of the PPM as an 8-bit RGB PNG (include/skr.h skr_write_png)."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w, _ = rgb.shape
+    _check(lib().skr_write_png(os.fsencode(path), w, h, rgb.ctypes.data), "skr_write_png")
+
+
+def write_pfm(path, rgbf):
+    """The unquantised float frame [H, W, 3] (top row first) as a PFM file (include/skr.h skr_write_pfm)."""
+    rgbf = np.ascontiguousarray(rgbf, np.float32)
+    h, w, _ = rgbf.shape
+    _check(lib().skr_write_pfm(os.fsencode(path), w, h, rgbf.ctypes.data), "skr_write_pfm")
+
+
 class Renderer:
     """Device context (scene resident in HBM) + the launches.  Needs a gfx950 GPU."""
 
@@ -286,6 +310,19 @@ class Renderer:
             _check(lib().skr_render_rows(self.h, C.byref(opt.c), y0, y1, rgb.data_ptr(),
                                          rgbf.data_ptr() if want_float else None, stream), "skr_render_rows")
         return rgb, rgbf
+
+    def render_progressive_host(self, opt, every=0, want_float=False, progress=None):
+        """include/skr.h skr_render_progressive_host: the whole frame (the mean of opt's progressive passes) into host arrays;
+        progress(passes_done, passes, rgb, rgbf) is called after every `every` passes with the mean so far (views of the
+        returned arrays; return True to stop).  Returns (rgb uint8 [H, W, 3], rgbf float32 or None, device ms)."""
+        self._sync_switches()
+        rgb = np.zeros((opt.height, opt.width, 3), np.uint8)
+        rgbf = np.zeros((opt.height, opt.width, 3), np.float32) if want_float else None
+        cb = PROGRESS_FN((lambda user, done, total, b, f: int(bool(progress(done, total, rgb, rgbf)))) if progress else (lambda *a: 0))
+        ms = C.c_float()
+        _check(lib().skr_render_progressive_host(self.h, C.byref(opt.c), every, rgb.ctypes.data, rgbf.ctypes.data if want_float else None,
+                                                 cb if progress else PROGRESS_FN(), None, C.byref(ms)), "skr_render_progressive_host")
+        return rgb, rgbf, ms.value
 
     def counters(self, reset=True):
         out = (C.c_uint64 * 3)()

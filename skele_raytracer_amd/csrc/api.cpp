@@ -14,6 +14,10 @@
 
 hipError_t skr_launch_render(const RenderParams &p, hipStream_t stream, const char **variant, const SkrTimingHook *hook);
 hipError_t skr_launch_debug(int op, const void *d_in, void *d_out, uint32_t n, hipStream_t stream);
+// accumulate.hip
+hipError_t skr_launch_accumulate(float *acc, const float *frame, size_t n, int first, hipStream_t stream);
+hipError_t skr_launch_resolve_accumulated(const float *acc, uint32_t passes, uint32_t width, uint32_t out_rows, uint32_t height, uint32_t tile_rows,
+										  uint32_t first_tile, uint32_t tile_stride, uint8_t *rgb, float *rgbf, hipStream_t stream);
 size_t skr_render_lds_bytes(const RenderParams &p);
 bool skr_queue_selected(const RenderParams &p);
 void skr_queue_scratch_bytes(const RenderParams &p, size_t *parent_bytes, size_t *acc_bytes);
@@ -53,6 +57,8 @@ struct skr_renderer {
 	size_t parents_cap = 0;
 	float *d_acc = nullptr;
 	size_t acc_cap = 0;
+	float *d_prog = nullptr; // progressive accumulation: this pass's float frame | the running sum
+	size_t prog_cap = 0;
 	uint8_t *d_frame = nullptr; // skr_render_frame_host
 	size_t frame_cap = 0;
 	hipEvent_t frame_e0 = nullptr, frame_e1 = nullptr;
@@ -167,6 +173,7 @@ void skr_renderer_destroy(skr_renderer *r)
 	if(r->d_levels) (void) hipFree(r->d_levels);
 	if(r->d_nodes) (void) hipFree(r->d_nodes);
 	if(r->d_acc) (void) hipFree(r->d_acc);
+	if(r->d_prog) (void) hipFree(r->d_prog);
 	if(r->d_frame) (void) hipFree(r->d_frame);
 	if(r->frame_e0) (void) hipEventDestroy(r->frame_e0);
 	if(r->frame_e1) (void) hipEventDestroy(r->frame_e1);
@@ -203,7 +210,8 @@ static int check_options(const skr_options *opt)
 	return SKR_OK;
 }
 
-static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t first_tile, uint32_t tile_stride,
+// one frame (one pass of a progressive render) of the tiles first_tile, first_tile + tile_stride, ...
+static int render_pass(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t first_tile, uint32_t tile_stride,
 					   uint32_t max_tiles, uint8_t *d_rgb, float *d_rgbf, void *stream)
 {
 	if(!r || !opt || (!d_rgb && !d_rgbf) || tile_rows == 0 || tile_stride == 0)
@@ -396,10 +404,82 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	return SKR_OK;
 }
 
+// grows the renderer's progressive scratch to 2 x n floats: this pass's frame | the running sum
+static int ensure_progressive_scratch(skr_renderer *r, size_t n)
+{
+	if(2 * n * sizeof(float) > r->prog_cap)
+	{
+		if(r->d_prog) SKR_HIP(hipFree(r->d_prog));
+		r->d_prog = nullptr;
+		r->prog_cap = 0;
+		SKR_HIP(hipMalloc((void **) &r->d_prog, 2 * n * sizeof(float)));
+		r->prog_cap = 2 * n * sizeof(float);
+	}
+	return SKR_OK;
+}
+
+// skr_options.progressive_passes: K frames under the seeds s, s+1, ..., s+K-1, summed in binary32 in pass
+// order, divided by K once and quantised like a single frame (accumulate.hip).  K <= 1 is the single frame itself.
+static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t first_tile, uint32_t tile_stride,
+					   uint32_t max_tiles, uint8_t *d_rgb, float *d_rgbf, void *stream)
+{
+	if(!opt || opt->progressive_passes <= 1) return render_pass(r, opt, tile_rows, first_tile, tile_stride, max_tiles, d_rgb, d_rgbf, stream);
+	if(!r || (!d_rgb && !d_rgbf) || tile_rows == 0 || tile_stride == 0)
+	{
+		skr_set_error("skr_render_tiles: bad argument");
+		return SKR_ERR_ARG;
+	}
+	int rc = check_options(opt);
+	if(rc != SKR_OK) return rc;
+	uint32_t n_tiles = skr_tile_count(opt, tile_rows, first_tile, tile_stride);
+	if(n_tiles > max_tiles) n_tiles = max_tiles;
+	if(n_tiles == 0) return SKR_OK;
+	SKR_HIP(hipSetDevice(r->device));
+	const uint32_t out_rows = n_tiles * tile_rows;
+	const size_t n = (size_t) opt->width * out_rows * 3;
+	rc = ensure_progressive_scratch(r, n);
+	if(rc != SKR_OK) return rc;
+	float *frame = r->d_prog, *acc = r->d_prog + n;
+	skr_options pass = *opt;
+	pass.progressive_passes = 1;
+	for(int32_t k = 0; k < opt->progressive_passes; k++)
+	{
+		pass.seed = opt->seed + (uint64_t) k;
+		rc = render_pass(r, &pass, tile_rows, first_tile, tile_stride, max_tiles, nullptr, frame, stream);
+		if(rc != SKR_OK) return rc;
+		SKR_HIP(skr_launch_accumulate(acc, frame, n, k == 0, (hipStream_t) stream));
+	}
+	SKR_HIP(skr_launch_resolve_accumulated(acc, (uint32_t) opt->progressive_passes, (uint32_t) opt->width, out_rows, (uint32_t) opt->height, tile_rows, first_tile,
+										   tile_stride, d_rgb, d_rgbf, (hipStream_t) stream));
+	return SKR_OK;
+}
+
 int skr_render_tiles(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t first_tile, uint32_t tile_stride,
 					 uint8_t *d_rgb, float *d_rgbf, void *stream)
 {
 	return render_impl(r, opt, tile_rows, first_tile, tile_stride, 0xffffffffu, d_rgb, d_rgbf, stream);
+}
+
+int skr_accumulate(float *d_acc, const float *d_frame, uint64_t n_floats, int first, void *stream)
+{
+	if(!d_acc || !d_frame)
+	{
+		skr_set_error("skr_accumulate: null argument");
+		return SKR_ERR_ARG;
+	}
+	SKR_HIP(skr_launch_accumulate(d_acc, d_frame, (size_t) n_floats, first, (hipStream_t) stream));
+	return SKR_OK;
+}
+
+int skr_resolve_accumulated(const float *d_acc, uint32_t passes, uint32_t width, uint32_t height, uint8_t *d_rgb, float *d_rgbf, void *stream)
+{
+	if(!d_acc || passes == 0 || (!d_rgb && !d_rgbf))
+	{
+		skr_set_error("skr_resolve_accumulated: bad argument");
+		return SKR_ERR_ARG;
+	}
+	SKR_HIP(skr_launch_resolve_accumulated(d_acc, passes, width, height, height, height ? height : 1, 0, 1, d_rgb, d_rgbf, (hipStream_t) stream));
+	return SKR_OK;
 }
 
 int skr_render_rows(skr_renderer *r, const skr_options *opt, uint32_t y0, uint32_t y1, uint8_t *d_rgb, float *d_rgbf, void *stream)
@@ -528,32 +608,82 @@ int skr_renderer_read_work(skr_renderer *r, uint64_t out[4], int reset)
 	return SKR_OK;
 }
 
-int skr_render_frame_host(skr_renderer *r, const skr_options *opt, uint8_t *h_rgb, float *kernel_ms)
+int skr_render_progressive_host(skr_renderer *r, const skr_options *opt, uint32_t every, uint8_t *h_rgb, float *h_rgbf, skr_progress_fn progress, void *user,
+								float *kernel_ms)
 {
-	if(!r || !opt || !h_rgb) return SKR_ERR_ARG;
+	if(!r || !opt || (!h_rgb && !h_rgbf))
+	{
+		skr_set_error("skr_render_progressive_host: bad argument");
+		return SKR_ERR_ARG;
+	}
 	int rc = check_options(opt); // before anything is sized from width x height
 	if(rc != SKR_OK) return rc;
 	SKR_HIP(hipSetDevice(r->device));
-	const size_t bytes = (size_t) opt->width * opt->height * 3;
-	if(bytes > r->frame_cap)
-	{ // the device frame and the two events live in the renderer: nothing to leak on an early return
+	const size_t pixels = (size_t) opt->width * opt->height, bytes = pixels * 3, fbytes = h_rgbf ? pixels * 12 : 0;
+	if(bytes + fbytes > r->frame_cap)
+	{ // the device frame (u8, then float) and the two events live in the renderer: nothing to leak on an early return
 		if(r->d_frame) SKR_HIP(hipFree(r->d_frame));
 		r->d_frame = nullptr;
 		r->frame_cap = 0;
-		SKR_HIP(hipMalloc((void **) &r->d_frame, bytes));
-		r->frame_cap = bytes;
+		SKR_HIP(hipMalloc((void **) &r->d_frame, ((bytes + 15) & ~(size_t) 15) + pixels * 12));
+		r->frame_cap = bytes + pixels * 12;
 	}
+	uint8_t *d_rgb = r->d_frame;
+	float *d_rgbf = h_rgbf ? reinterpret_cast<float *>(r->d_frame + ((bytes + 15) & ~(size_t) 15)) : nullptr;
 	if(!r->frame_e0) SKR_HIP(hipEventCreate(&r->frame_e0));
 	if(!r->frame_e1) SKR_HIP(hipEventCreate(&r->frame_e1));
-	SKR_HIP(hipEventRecord(r->frame_e0, nullptr));
-	rc = skr_render_tiles(r, opt, (uint32_t) opt->height, 0, 1, r->d_frame, nullptr, nullptr);
+	const uint32_t passes = opt->progressive_passes > 1 ? (uint32_t) opt->progressive_passes : 1u;
+	float total_ms = 0;
+	if(!progress || every == 0 || every >= passes)
+	{ // nobody looks before the end: the frame (or the K-pass mean) in one launch sequence
+		SKR_HIP(hipEventRecord(r->frame_e0, nullptr));
+		rc = skr_render_tiles(r, opt, (uint32_t) opt->height, 0, 1, d_rgb, d_rgbf, nullptr);
+		if(rc != SKR_OK) return rc;
+		SKR_HIP(hipEventRecord(r->frame_e1, nullptr));
+		if(h_rgb) SKR_HIP(hipMemcpy(h_rgb, d_rgb, bytes, hipMemcpyDeviceToHost));
+		if(h_rgbf) SKR_HIP(hipMemcpy(h_rgbf, d_rgbf, fbytes, hipMemcpyDeviceToHost));
+		SKR_HIP(hipEventElapsedTime(&total_ms, r->frame_e0, r->frame_e1));
+		if(progress) (void) progress(user, passes, passes, h_rgb, h_rgbf);
+		if(kernel_ms) *kernel_ms = total_ms;
+		return SKR_OK;
+	}
+	// the mean is shown while it forms: after every `every` passes (and after the last) it is resolved, copied out and handed to
+	// the callback — where the SDL viewer of main.cpp:183-197 would blit.  The final mean is the one-launch result, bit for bit.
+	const size_t n = pixels * 3;
+	rc = ensure_progressive_scratch(r, n);
 	if(rc != SKR_OK) return rc;
-	SKR_HIP(hipEventRecord(r->frame_e1, nullptr));
-	SKR_HIP(hipMemcpy(h_rgb, r->d_frame, bytes, hipMemcpyDeviceToHost));
-	float ms = 0;
-	SKR_HIP(hipEventElapsedTime(&ms, r->frame_e0, r->frame_e1));
-	if(kernel_ms) *kernel_ms = ms;
+	float *frame = r->d_prog, *acc = r->d_prog + n;
+	skr_options pass = *opt;
+	pass.progressive_passes = 1;
+	for(uint32_t k = 0; k < passes; k++)
+	{
+		pass.seed = opt->seed + (uint64_t) k;
+		SKR_HIP(hipEventRecord(r->frame_e0, nullptr));
+		rc = render_pass(r, &pass, (uint32_t) opt->height, 0, 1, 0xffffffffu, nullptr, frame, nullptr);
+		if(rc != SKR_OK) return rc;
+		SKR_HIP(skr_launch_accumulate(acc, frame, n, k == 0, nullptr));
+		const bool show = (k + 1) % every == 0 || k + 1 == passes;
+		if(show) SKR_HIP(skr_launch_resolve_accumulated(acc, k + 1, (uint32_t) opt->width, (uint32_t) opt->height, (uint32_t) opt->height, (uint32_t) opt->height, 0, 1, d_rgb, d_rgbf, nullptr));
+		SKR_HIP(hipEventRecord(r->frame_e1, nullptr));
+		if(show)
+		{
+			if(h_rgb) SKR_HIP(hipMemcpy(h_rgb, d_rgb, bytes, hipMemcpyDeviceToHost));
+			if(h_rgbf) SKR_HIP(hipMemcpy(h_rgbf, d_rgbf, fbytes, hipMemcpyDeviceToHost));
+		}
+		else SKR_HIP(hipEventSynchronize(r->frame_e1));
+		float ms = 0;
+		SKR_HIP(hipEventElapsedTime(&ms, r->frame_e0, r->frame_e1));
+		total_ms += ms;
+		if(show && progress(user, k + 1, passes, h_rgb, h_rgbf) != 0) break; // the viewer was closed: what is in the buffers is the mean so far
+	}
+	if(kernel_ms) *kernel_ms = total_ms;
 	return SKR_OK;
+}
+
+int skr_render_frame_host(skr_renderer *r, const skr_options *opt, uint8_t *h_rgb, float *kernel_ms)
+{
+	if(!h_rgb) return SKR_ERR_ARG;
+	return skr_render_progressive_host(r, opt, 0, h_rgb, nullptr, nullptr, nullptr, kernel_ms);
 }
 
 const char *skr_kernel_variant(void) { return g_variant; }

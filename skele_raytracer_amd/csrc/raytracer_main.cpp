@@ -4,7 +4,8 @@
 // Flags are matched by strcmp anywhere in argv and unknown tokens are ignored,
 // messages and the exit-status-0 convention follow the reference.  New,
 // non-colliding flags: --seed u64 (counter-RNG key; the reference seeds rand()
-// with time(0)), --device i, --quiet (no per-line scene echo).
+// with time(0)), --device i, --quiet (no per-line scene echo), --gpus N, --strict-scn,
+// --shade-triangles, --progressive K [--progressive-every M], --format ppm|png|pfm.
 // The frame itself is rendered by libskr on the GPU; there is no CPU path here.
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +26,8 @@ int main(int argc, char *argv[])
 	bool strict_scn = false, width_given = false, height_given = false, depth_given = false; // --strict-scn (new)
 	bool sharded = false; // --gpus given (even --gpus 1): the frame goes through the multi-GPU path
 	uint32_t tile_rows = 8;
+	uint32_t progressive_every = 0; // --progressive-every M: the output file is rewritten after every M passes (the headless "viewer")
+	const char *format = "ppm";     // --format ppm | png | pfm (new; the reference writes P6 whatever the name says)
 
 	for(int i = 0; i < argc; i++)
 	{
@@ -117,6 +120,9 @@ int main(int argc, char *argv[])
 		if(!strcmp(argv[i], "--quiet")) quiet = true;
 		if(!strcmp(argv[i], "--strict-scn")) strict_scn = true;
 		if(!strcmp(argv[i], "--shade-triangles")) option.shade_triangles = 1; // new: triangles as surfaces (include/skr.h skr_options)
+		if(!strcmp(argv[i], "--progressive") && has_next) option.progressive_passes = atoi(argv[i + 1]) > 1 ? atoi(argv[i + 1]) : 1; // new: mean of K frames, seeds seed..seed+K-1
+		if(!strcmp(argv[i], "--progressive-every") && has_next) progressive_every = (uint32_t) (atoi(argv[i + 1]) > 0 ? atoi(argv[i + 1]) : 0);
+		if(!strcmp(argv[i], "--format") && has_next) format = argv[i + 1];
 	}
 	if(!path)
 	{
@@ -153,7 +159,27 @@ int main(int argc, char *argv[])
 		std::cerr << "raytracer: bad image size " << option.width << "x" << option.height << std::endl;
 		return SKR_ERR_ARG;
 	}
+	const bool want_pfm = !strcmp(format, "pfm"), want_png = !strcmp(format, "png");
+	if(!want_pfm && !want_png && strcmp(format, "ppm"))
+	{
+		std::cerr << "format takes ppm, png or pfm" << std::endl;
+		return 0;
+	}
+	if(sharded && (want_pfm || progressive_every))
+	{ // the ranks exchange quantised tiles (one all-gather of bytes): the float frame and the running mean stay on their devices
+		std::cerr << "raytracer: --format pfm and --progressive-every need the single-device path (drop --gpus)" << std::endl;
+		return SKR_ERR_ARG;
+	}
 	std::vector<uint8_t> rgb((size_t) option.width * option.height * 3);
+	std::vector<float> rgbf(want_pfm ? rgb.size() : 0);
+	struct Out {
+		const char *path;
+		uint32_t w, h;
+		bool pfm, png, quiet;
+	} out{output, (uint32_t) option.width, (uint32_t) option.height, want_pfm, want_png, quiet};
+	auto write_out = [](const Out &o, const uint8_t *b, const float *f) {
+		return o.pfm ? skr_write_pfm(o.path, o.w, o.h, f) : o.png ? skr_write_png(o.path, o.w, o.h, b) : skr_write_ppm(o.path, o.w, o.h, b);
+	};
 	float ms = 0;
 	uint64_t counters[3] = {0, 0, 0};
 	int rc;
@@ -177,8 +203,22 @@ int main(int argc, char *argv[])
 	}
 	else
 	{
+		// --progressive-every: the file is the window (main.cpp:183-197 redraws its SDL window as rows finish) — rewritten with the
+		// mean so far after every M passes
+		struct Show {
+			const Out *o;
+			int (*write)(const Out &, const uint8_t *, const float *);
+		} show{&out, write_out};
+		skr_progress_fn progress = [](void *user, uint32_t done, uint32_t passes, const uint8_t *b, const float *f) -> int {
+			const Show *s = static_cast<const Show *>(user);
+			if(done < passes && s->write(*s->o, b, f) != SKR_OK) return 1;
+			if(!s->o->quiet) printf("pass %u of %u\n", done, passes);
+			return 0;
+		};
 		rc = skr_renderer_create(scene, device, &renderer);
-		if(rc == SKR_OK) rc = skr_render_frame_host(renderer, &option, rgb.data(), &ms);
+		if(rc == SKR_OK)
+			rc = skr_render_progressive_host(renderer, &option, progressive_every, want_pfm ? nullptr : rgb.data(), want_pfm ? rgbf.data() : nullptr,
+											 progressive_every ? progress : nullptr, &show, &ms);
 		if(rc != SKR_OK)
 		{
 			std::cerr << "raytracer: " << skr_last_error() << std::endl;
@@ -186,7 +226,7 @@ int main(int argc, char *argv[])
 		}
 		skr_renderer_read_counters(renderer, counters, 0);
 	}
-	rc = skr_write_ppm(output, (uint32_t) option.width, (uint32_t) option.height, rgb.data());
+	rc = write_out(out, rgb.data(), rgbf.data());
 	if(rc != SKR_OK)
 	{
 		std::cerr << "raytracer: " << skr_last_error() << std::endl;

@@ -762,6 +762,7 @@ void skr_options_default(skr_options *opt)
 	opt->use_shadows = 0;
 	opt->seed = 1;
 	opt->shade_triangles = 0;
+	opt->progressive_passes = 1;
 }
 
 uint64_t skr_radiance_ray_count(const skr_options *opt)
@@ -775,7 +776,8 @@ uint64_t skr_radiance_ray_count(const skr_options *opt)
 		if(!opt->monte_carlo) break;
 		pw *= (uint64_t) (opt->num_path_traces > 0 ? opt->num_path_traces : 0);
 	}
-	return (uint64_t) opt->width * opt->height * S * per;
+	const uint64_t K = opt->progressive_passes > 1 ? (uint64_t) opt->progressive_passes : 1; // every pass is a whole frame
+	return (uint64_t) opt->width * opt->height * S * per * K;
 }
 
 // main.cpp:199-211: "P6\n" W " " H "\n255\n" then W*H*3 bytes, top row first.
@@ -790,6 +792,104 @@ int skr_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8
 	}
 	ofs << "P6\n" << width << " " << height << "\n255\n";
 	ofs.write(reinterpret_cast<const char *>(rgb), (std::streamsize) width * height * 3);
+	ofs.close();
+	return ofs ? SKR_OK : SKR_ERR_IO;
+}
+
+// ---- other outputs.  The reference writes P6 only (main.cpp:199-211). ----
+
+// Portable float map: "PF\n<W> <H>\n-1.0\n" (negative scale = little-endian), then W*3 binary32 values per row, BOTTOM row
+// first.  Carries the unquantised frame (what main.cpp:205 clamps away): rgbf is top row first, like every buffer here.
+int skr_write_pfm(const char *path, uint32_t width, uint32_t height, const float *rgbf)
+{
+	if(!path || !rgbf) return SKR_ERR_ARG;
+	std::ofstream ofs(path, std::ios::out | std::ios::binary);
+	if(!ofs)
+	{
+		skr_set_error("cannot open '%s' for writing", path);
+		return SKR_ERR_IO;
+	}
+	ofs << "PF\n" << width << " " << height << "\n-1.0\n";
+	for(uint32_t y = height; y-- > 0;) ofs.write(reinterpret_cast<const char *>(rgbf + (size_t) y * width * 3), (std::streamsize) width * 12);
+	ofs.close();
+	return ofs ? SKR_OK : SKR_ERR_IO;
+}
+
+// PNG, 8-bit RGB, the bytes of the PPM: filter 0 on every row, zlib stream of stored (uncompressed) deflate blocks — no
+// compressor is linked; any PNG reader takes it.
+int skr_write_png(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb)
+{
+	if(!path || !rgb || width == 0 || height == 0) return SKR_ERR_ARG;
+	static uint32_t crc_table[256];
+	static bool have_table = false;
+	if(!have_table)
+	{
+		for(uint32_t n = 0; n < 256; n++)
+		{
+			uint32_t c = n;
+			for(int k = 0; k < 8; k++) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+			crc_table[n] = c;
+		}
+		have_table = true;
+	}
+	auto be32 = [](std::vector<uint8_t> &v, uint32_t x) { for(int k = 3; k >= 0; k--) v.push_back((uint8_t) (x >> (8 * k))); };
+	std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+	auto chunk = [&](const char type[4], const std::vector<uint8_t> &data) {
+		be32(out, (uint32_t) data.size());
+		const size_t at = out.size();
+		out.insert(out.end(), type, type + 4);
+		out.insert(out.end(), data.begin(), data.end());
+		uint32_t c = 0xffffffffu;
+		for(size_t i = at; i < out.size(); i++) c = crc_table[(c ^ out[i]) & 0xffu] ^ (c >> 8);
+		be32(out, c ^ 0xffffffffu);
+	};
+	std::vector<uint8_t> ihdr;
+	be32(ihdr, width);
+	be32(ihdr, height);
+	const uint8_t tail[5] = {8, 2, 0, 0, 0}; // bit depth 8, colour type 2 (RGB), deflate, adaptive filtering, no interlace
+	ihdr.insert(ihdr.end(), tail, tail + 5);
+	chunk("IHDR", ihdr);
+	const size_t row = (size_t) width * 3 + 1, raw_n = row * height;
+	if(raw_n > 0x7fffffffull)
+	{
+		skr_set_error("skr_write_png: image too large for one IDAT chunk");
+		return SKR_ERR_ARG;
+	}
+	std::vector<uint8_t> raw(raw_n);
+	for(uint32_t y = 0; y < height; y++)
+	{
+		raw[row * y] = 0;
+		memcpy(&raw[row * y + 1], rgb + (size_t) y * width * 3, (size_t) width * 3);
+	}
+	std::vector<uint8_t> z = {0x78, 0x01};
+	uint32_t a = 1, b = 0; // adler32
+	for(size_t at = 0; at < raw_n; at += 65535)
+	{
+		const size_t len = raw_n - at < 65535 ? raw_n - at : 65535;
+		z.push_back(at + len == raw_n ? 1 : 0);
+		z.push_back((uint8_t) len);
+		z.push_back((uint8_t) (len >> 8));
+		z.push_back((uint8_t) ~len);
+		z.push_back((uint8_t) (~len >> 8));
+		z.insert(z.end(), raw.begin() + (ptrdiff_t) at, raw.begin() + (ptrdiff_t) (at + len));
+		for(size_t i = at; i < at + len;)
+		{ // 5552 bytes: the longest run before a + b can overflow 32 bits
+			const size_t stop = i + 5552 < at + len ? i + 5552 : at + len;
+			for(; i < stop; i++) { a += raw[i]; b += a; }
+			a %= 65521u;
+			b %= 65521u;
+		}
+	}
+	be32(z, (b << 16) | a);
+	chunk("IDAT", z);
+	chunk("IEND", {});
+	std::ofstream ofs(path, std::ios::out | std::ios::binary);
+	if(!ofs)
+	{
+		skr_set_error("cannot open '%s' for writing", path);
+		return SKR_ERR_IO;
+	}
+	ofs.write(reinterpret_cast<const char *>(out.data()), (std::streamsize) out.size());
 	ofs.close();
 	return ofs ? SKR_OK : SKR_ERR_IO;
 }

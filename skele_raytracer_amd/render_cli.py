@@ -3,6 +3,7 @@ per GPU.
 
     python -m skele_raytracer_amd.render_cli --path S.scn --output O.ppm [--width i] [--height i] [--fov f]
            [--gillum n] [--jsample g] [--depth d] [--parallel true|false] [--shadow] [--seed N] [--tile-rows r]
+           [--strict-scn] [--shade-triangles] [--progressive K [--progressive-every M]] [--format ppm|png|pfm]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
            -m skele_raytracer_amd.render_cli --path spheres2.scn --output out.ppm --width 3840 --height 2160 \\
            --gillum 64 --jsample 5 --shadow            # BASELINE config 5
@@ -77,12 +78,20 @@ def _parse(argv):
             opt["strict_scn"] = True
         elif a == "--shade-triangles":
             opt["shade_triangles"] = True
+        elif a == "--progressive":
+            opt["progressive"] = max(1, value(i, _atoi, "progressive takes the number of passes"))
+        elif a == "--progressive-every":
+            opt["progressive_every"] = max(0, value(i, _atoi, "progressive-every takes a number of passes"))
+        elif a == "--format":
+            opt["format"] = value(i, str, "format takes ppm, png or pfm")
         elif a == "--seed":
             opt["seed"] = value(i, _atoi, "seed takes an int")
         elif a == "--tile-rows":
             opt["tile_rows"] = value(i, _atoi, "tile-rows takes a positive int")
     if opt["tile_rows"] <= 0:
         raise ValueError("tile-rows takes a positive int")
+    if opt.get("format", "ppm") not in ("ppm", "png", "pfm"):
+        raise ValueError("format takes ppm, png or pfm")
     if opt.get("strict_scn"):
         opt["_given"] = given
     if opt["path"] is None:
@@ -141,12 +150,39 @@ def main(argv=None):
         if "depth" not in o["_given"] and info.max_depth_parsed > 0:
             o["depth"] = info.max_depth_parsed
     r = skr.Renderer(scene, local_rank)
-    kw = dict(fov=o["fov"], depth=o["depth"], shadow=o["shadow"], seed=o["seed"], shade_triangles=bool(o.get("shade_triangles")))
+    kw = dict(fov=o["fov"], depth=o["depth"], shadow=o["shadow"], seed=o["seed"], shade_triangles=bool(o.get("shade_triangles")), progressive=o.get("progressive", 1))
     if o["gillum"] is not None:
         kw["gillum"] = o["gillum"]
     if o["jsample"] is not None:
         kw["jsample"] = o["jsample"]
     opt = skr.Options(o["width"], o["height"], **kw)
+    fmt, every = o.get("format", "ppm"), o.get("progressive_every", 0)
+    if world > 1 and (fmt == "pfm" or every):
+        # the ranks exchange quantised tiles (one all-gather of bytes): the float frame and the running mean stay on their devices
+        if rank == 0:
+            print("raytracer: --format pfm and --progressive-every need the single-device path", file=sys.stderr)
+        dist.destroy_process_group()
+        return 2
+    if fmt == "pfm" or every:
+        # the file is the window (main.cpp:183-197 redraws its SDL window as rows finish): rewritten with the mean so far
+        def write(rgb, rgbf):
+            if fmt == "pfm":
+                skr.write_pfm(o["output"], rgbf)
+            else:
+                (skr.write_png if fmt == "png" else skr.write_ppm)(o["output"], rgb)
+
+        def progress(done, total, rgb, rgbf):
+            if done < total:
+                write(rgb, rgbf)
+            print("pass %d of %d" % (done, total))
+            return False
+
+        opt = skr.Options(o["width"], o["height"], **kw)
+        rgb, rgbf, ms = r.render_progressive_host(opt, every, want_float=(fmt == "pfm"), progress=progress if every else None)
+        write(rgb, rgbf)
+        print("***\nWROTE TO PPM\n***")  # main.cpp:213
+        print("1 GPU(s), %dx%d, %.3f ms (device), kernel %s" % (o["width"], o["height"], ms, r.kernel_variant()), file=sys.stderr)
+        return 0
     sharder = FrameSharder(o["width"], o["height"], o["tile_rows"], rank, world, dev)
     stream = torch.cuda.current_stream(dev)
     t0 = time.perf_counter()
@@ -154,7 +190,7 @@ def main(argv=None):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     if rank == 0:
-        skr.write_ppm(o["output"], frame.cpu().numpy())
+        (skr.write_png if fmt == "png" else skr.write_ppm)(o["output"], frame.cpu().numpy())
         print("***\nWROTE TO PPM\n***")  # main.cpp:213
         print("%d GPU(s), %dx%d, %.3f ms (render + gather), kernel %s" % (world, o["width"], o["height"], dt * 1e3, r.kernel_variant()), file=sys.stderr)
     if world > 1:
