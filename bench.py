@@ -38,7 +38,7 @@ TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
 # the files whose contents decide what the kernels move: the measured traffic is only reported for the exact sources it was measured on
 KERNEL_SOURCES = ["skele_raytracer_amd/csrc/render_nodes.hip", "skele_raytracer_amd/csrc/render_wave.hip", "skele_raytracer_amd/csrc/wave_common.h",
                   "skele_raytracer_amd/csrc/shade_common.h", "skele_raytracer_amd/csrc/device_math.h", "skele_raytracer_amd/csrc/render_params.h"]
-DOMINANT = {"node_levels_v5": "skr_leaf_kernel2<false, false>", "level_queues_v4": "skr_leaf_kernel<false>", "parent_queue_v3": "skr_gi_kernel<3, 3, false>",
+DOMINANT = {"node_levels_v5": "skr_leaf_kernel2<false, false>", "node_levels_v5_flat": "skr_trace_kernel<false> (last level) + skr_shade_leaf_kernel<false>", "level_queues_v4": "skr_leaf_kernel<false>", "parent_queue_v3": "skr_gi_kernel<3, 3, false>",
             "wave_streaming_v2": "skr_wave_kernel<3, 3>"}
 
 

@@ -82,6 +82,7 @@ static void load_switches(SkrSwitches &sw)
 	sw.no_cones = getenv("SKR_NO_CONES") != nullptr;
 	sw.no_cull = getenv("SKR_NO_CULL") != nullptr;
 	if(const char *e = getenv("SKR_LEVELS_BUDGET_MB")) sw.budget_mb = atoi(e) > 0 ? atoi(e) : 1;
+	if(const char *e = getenv("SKR_FLAT")) sw.flat = atoi(e) > 0 ? 1 : -1;
 }
 
 extern "C" {

@@ -326,6 +326,7 @@ hipError_t skr_launch_levels(const RenderParams &p, hipStream_t stream, const Sk
 hipError_t skr_launch_queue(const RenderParams &p, hipStream_t stream, const SkrTimingHook *hook);
 // render_nodes.hip
 bool skr_nodes_selected(const RenderParams &p);
+bool skr_nodes_flat(const RenderParams &p);
 size_t skr_nodes_lds_bytes(const RenderParams &p);
 hipError_t skr_launch_nodes(const RenderParams &p, hipStream_t stream, const SkrTimingHook *hook);
 
@@ -356,7 +357,7 @@ hipError_t skr_launch_render(const RenderParams &p, hipStream_t stream, const ch
 {
 	if(skr_nodes_selected(p) && p.node_scratch)
 	{
-		*variant = "node_levels_v5";
+		*variant = skr_nodes_flat(p) ? "node_levels_v5_flat" : "node_levels_v5";
 		return skr_launch_nodes(p, stream, hook);
 	}
 	if(use_wave_kernel(p))

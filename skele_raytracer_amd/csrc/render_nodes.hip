@@ -112,12 +112,16 @@ __global__ __launch_bounds__(256) void skr_trace_kernel(const RenderParams p)
 	if((uint64_t) blockIdx.x * 256u >= n_pairs) return; // (uniform per workgroup)
 	const SceneView sv = stage_scene(p, lds4, TRIS);
 	const int tid = threadIdx.x, lane = tid & 63;
-	const uint32_t chunk = (uint32_t) blockIdx.x * 4u + (uint32_t) (tid >> 6);
+	Counters cn{0, 0, 0};
+	// (the grid is sized for the worst case — every ray of the level above a hit — and capped: a workgroup takes every
+	// gridDim.x-th block of 256 pairs, so a launch far below the worst case does not pay for its empty workgroups)
+	for(uint32_t blk = blockIdx.x; (uint64_t) blk * 256u < n_pairs; blk += gridDim.x)
+	{
+	const uint32_t chunk = blk * 4u + (uint32_t) (tid >> 6);
 	const uint64_t tp = (uint64_t) chunk * 64u + (uint32_t) lane;
 	const bool valid = tp < n_pairs;
 	const uint32_t node = valid ? (uint32_t) (tp / PP) : 0u, j = valid ? (uint32_t) (tp - (uint64_t) node * PP) : 0u;
 	const bool second = valid && 2u * j + 1u < N;
-	Counters cn{0, 0, 0};
 	bool hit0 = false, hit1 = false;
 	float4 rec0 = make_float4(0, 0, 0, 0), rec1 = rec0;
 	bool black0 = false, black1 = false;
@@ -161,24 +165,36 @@ __global__ __launch_bounds__(256) void skr_trace_kernel(const RenderParams p)
 	if(hit1) p.rc[rec_base + n0h + rank1] = rec1;
 	if(valid) p.ix16[tp] = (uint16_t) ((hit0 ? PC_HIT0 : 0u) | (hit1 ? PC_HIT1 : 0u) | (black0 ? PC_BLACK0 : 0u) | (black1 ? PC_BLACK1 : 0u) | (rank0 << 4) | (rank1 << 10));
 	if(lane == 0) p.ixh[chunk] = make_uint2(rec_base, n0h);
-	add_counters(p, cn, chunk, lane);
+	}
+	add_counters(p, cn, (uint32_t) blockIdx.x * 4u + (uint32_t) (tid >> 6), lane);
 }
 
-// One wave: prefix sums of a level's 64 region counts (dense node numbering of the activated records).
-__global__ __launch_bounds__(64) void skr_prefix_kernel(const RenderParams p)
+// Prefix sums of a level's 64 region counts (the dense numbering of its records), formed by the first wave of a workgroup
+// into 65 words of LDS: s_pre[r] = records before region r, s_pre[64] = all.  `publish`: also written behind the level's
+// counters, where the kernels launched later read the level's record count (lc_prefix_host).  Ends in a workgroup barrier.
+SKR_DEV void region_prefix(const RenderParams &p, uint32_t *s_pre, bool publish)
 {
-	const int lane = threadIdx.x;
-	uint32_t v = *lc_count(p.rc_ctr, (uint32_t) lane);
-	uint32_t incl = v;
-#pragma unroll
-	for(int off = 1; off < 64; off <<= 1)
+	if(threadIdx.x < 64)
 	{
-		const uint32_t o = (uint32_t) __shfl_up((int) incl, off, 64);
-		if(lane >= off) incl += o;
+		const int lane = threadIdx.x;
+		const uint32_t v = *lc_count(p.rc_ctr, (uint32_t) lane);
+		uint32_t incl = v;
+#pragma unroll
+		for(int off = 1; off < 64; off <<= 1)
+		{
+			const uint32_t o = (uint32_t) __shfl_up((int) incl, off, 64);
+			if(lane >= off) incl += o;
+		}
+		s_pre[lane] = incl - v;
+		if(lane == 63) s_pre[64] = incl;
+		if(publish)
+		{
+			uint32_t *pre = lc_prefix(p.rc_ctr);
+			pre[lane] = incl - v;
+			if(lane == 63) pre[64] = incl;
+		}
 	}
-	uint32_t *pre = lc_prefix(p.rc_ctr);
-	pre[lane] = incl - v;
-	if(lane == 63) pre[64] = incl;
+	__syncthreads();
 }
 
 // =====================================================================================================================
@@ -242,6 +258,9 @@ __global__ __launch_bounds__(256) void skr_activate_kernel(const RenderParams p)
 	const uint32_t per_region = (p.rc_cap + 255u) / 256u;
 	const uint32_t region = (uint32_t) blockIdx.x / per_region, pos0 = ((uint32_t) blockIdx.x % per_region) * 256u;
 	const uint32_t cnt = *lc_count(p.rc_ctr, region);
+	if(pos0 >= cnt && blockIdx.x != 0) return;
+	__shared__ uint32_t s_pre[65];
+	region_prefix(p, s_pre, blockIdx.x == 0); // (workgroup 0 leaves the level's record count for the kernels that follow)
 	if(pos0 >= cnt) return;
 	const SceneView sv = stage_scene(p, lds4, TRIS);
 	const uint32_t pos = pos0 + threadIdx.x;
@@ -251,11 +270,50 @@ __global__ __launch_bounds__(256) void skr_activate_kernel(const RenderParams p)
 	const Activated a = activate_record(sv, p, act, rec, cn);
 	if(act)
 	{
-		float4 *row = p.nd_dst + (size_t) (lc_prefix(p.rc_ctr)[region] + pos) * 4;
+		float4 *row = p.nd_dst + (size_t) (s_pre[region] + pos) * 4;
 		row[0] = make_float4(a.co.x, a.co.y, a.co.z, a.N.x);
 		row[1] = make_float4(a.N.y, a.N.z, a.direct.x, a.direct.y);
 		row[2] = make_float4(a.direct.z, __uint_as_float(a.pixel), __uint_as_float(a.node_id), __uint_as_float(a.sph));
 		row[3] = make_float4(a.r1, __uint_as_float(rec), 0.0f, 0.0f);
+	}
+	add_counters(p, cn, blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// Flat schedule (small launches): the hit records of the LAST level are shaded one per lane, no children (they are shade(depth 0)
+// == 0, raytrace.h:142-145): raytrace.h:194-213 with indirect = (0,0,0)/N, then the parent's accumulation term (:130) — the
+// arithmetic of leaf_batch() below, on records instead of ring entries.  Dense numbering through the level's prefix sums
+// (region_prefix): position i belongs to the region whose prefix range holds it.
+template <bool TRIS>
+__global__ __launch_bounds__(256) void skr_shade_leaf_kernel(const RenderParams p)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
+	__shared__ uint32_t prefix[65];
+	region_prefix(p, prefix, false);
+	const uint32_t total = prefix[64];
+	if((uint32_t) blockIdx.x * 256u >= total) return; // (uniform per workgroup)
+	const SceneView sv = stage_scene(p, lds4, TRIS);
+	const float pdf = (float) (1 / 3.14159265358979323846);
+	Counters cn{0, 0, 0};
+	for(uint32_t base = (uint32_t) blockIdx.x * 256u; base < total; base += gridDim.x * 256u)
+	{
+		const uint32_t i = base + threadIdx.x;
+		const bool act = i < total;
+		uint32_t lo = 0, hi = SKR_P1_REGIONS; // the region r with prefix[r] <= i < prefix[r + 1]
+		while(hi - lo > 1u)
+		{
+			const uint32_t mid = (lo + hi) >> 1;
+			if(prefix[mid] <= (act ? i : 0u)) lo = mid;
+			else hi = mid;
+		}
+		const uint32_t rec = lo * p.rc_cap + ((act ? i : 0u) - prefix[lo]);
+		const Activated a = activate_record(sv, p, act, rec, cn);
+		if(act)
+		{
+			const f3 tot = mk3(0, 0, 0) / (float) p.num_path_traces;
+			const f3 colour = (a.direct / (float) 3.14159265358979323846 + tot * 2.0f) * ld3(sv.kd[a.sph]);
+			store3(p.res_out + (size_t) rec * 3, (colour * a.r1) / pdf);
+		}
 	}
 	add_counters(p, cn, blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63);
 }
@@ -702,9 +760,16 @@ __global__ __launch_bounds__(256) void skr_finalize_kernel2(const RenderParams p
 hipError_t skr_launch_primary(const RenderParams &p, dim3 grid, size_t lds, hipStream_t stream); // render_wave.hip
 hipError_t skr_launch_resolve(const RenderParams &p, hipStream_t stream);
 
-constexpr int SKR_NODE_LEVELS_MAX = 32;
+constexpr int SKR_NODE_LEVELS_MAX = 33;
+#ifndef SKR_TRACE_GRID_MAX
+#define SKR_TRACE_GRID_MAX 49152u // workgroups of skr_trace_kernel at most (it strides over the blocks of 256 pairs)
+#endif
+#ifndef SKR_FLAT_BELOW
+#define SKR_FLAT_BELOW 1.2e8 // last-level rays (worst case) below which a launch takes the flat schedule: tools/ab_nodes.py, DESIGN.md 5.0n
+#endif
 struct NodePlan {
-	int levels = 0;          // node / record levels 0 .. max_depth - 2
+	bool flat = false;       // the flat schedule (below): the leaves' hits are a record level of their own
+	int levels = 0;          // node / record levels 0 .. max_depth - 2 (flat: .. max_depth - 1)
 	uint32_t band_nblk = 0;  // 16x16 pixel blocks per band
 	uint32_t stride0 = 3;    // float4 per level-0 node
 	uint64_t nodes_max[SKR_NODE_LEVELS_MAX] = {};
@@ -716,13 +781,27 @@ static uint32_t *lc_prefix_host(uint32_t *ctr) { return ctr + SKR_PULL_STRIDE * 
 static const uint32_t LEAF2_GRID = 256u * SKR_LEAF2_OCC;                   // every workgroup resident: 256 CUs x 4 workgroups of 4 waves
 static const size_t LVL_CTR_WORDS = (size_t) SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS + 2u); // counts, taken, mask, prefix
 
-static bool plan_for(const RenderParams &p, uint32_t nblk, NodePlan &pl)
+// Small launches (one rank's share of a frame cut over many GPUs) take the FLAT schedule: the last level too is traced by
+// skr_trace_kernel into records, which skr_shade_leaf_kernel shades — every kernel a plain grid, nothing persistent.  The
+// persistent leaf kernel has one or two units per wave on such a launch and ends a whole unit after its queues run dry
+// (a 1/8 headline frame: 66 % busy); on a full frame its ring and windows save the records' 1.2 GB of HBM traffic instead.
+// SKR_FLAT=1 / 0 forces one or the other (A/B runs).
+static bool nodes_flat_wanted(const RenderParams &p)
+{
+	if(p.sw.flat) return p.sw.flat > 0;
+	double rays = (double) p.width * p.out_rows; // rays of the last level if every ray hit
+	for(int k = 1; k < p.max_depth; k++) rays *= (double) p.num_path_traces;
+	return rays < SKR_FLAT_BELOW;
+}
+
+static bool plan_for(const RenderParams &p, uint32_t nblk, bool flat, NodePlan &pl)
 {
 	const uint64_t N = (uint64_t) p.num_path_traces, PP = (N + 1) >> 1;
-	pl.levels = p.max_depth - 1;
+	pl.flat = flat;
+	pl.levels = p.max_depth - 1 + (flat ? 1 : 0);
 	if(pl.levels < 1 || pl.levels > SKR_NODE_LEVELS_MAX) return false;
 	pl.band_nblk = nblk;
-	pl.stride0 = p.max_depth <= 3 ? 3u : 4u;
+	pl.stride0 = pl.levels <= 2 ? 3u : 4u; // (64-byte rows where skr_activate_kernel gathers its parents from them)
 	pl.nodes_max[0] = (uint64_t) nblk * 256u;
 	pl.cap[0] = 0;
 	for(int L = 1; L < pl.levels; L++)
@@ -765,21 +844,31 @@ static uint64_t nodes_budget(const RenderParams &p)
 }
 
 // the largest band (in 16x16 pixel blocks) whose worst-case tables fit the budget; false: not even one block does
-static bool skr_nodes_plan(const RenderParams &p, NodePlan &pl)
+static bool plan_bands(const RenderParams &p, bool flat, NodePlan &pl)
 {
 	const uint32_t bx = (uint32_t) (p.width + 15) / 16, by = (p.out_rows + 15) / 16;
 	const uint64_t budget = nodes_budget(p);
 	uint32_t lo = 1, hi = bx * by;
-	if(!plan_for(p, lo, pl) || pl.banded > budget) return false;
-	if(plan_for(p, hi, pl) && pl.banded <= budget) return true;
+	if(!plan_for(p, lo, flat, pl) || pl.banded > budget) return false;
+	if(plan_for(p, hi, flat, pl) && pl.banded <= budget) return true;
 	while(hi - lo > 1)
 	{ // plan size grows with the block count
 		const uint32_t mid = lo + (hi - lo) / 2;
-		if(plan_for(p, mid, pl) && pl.banded <= budget) lo = mid;
+		if(plan_for(p, mid, flat, pl) && pl.banded <= budget) lo = mid;
 		else hi = mid;
 	}
 	if(lo > bx) lo = lo / bx * bx; // whole block rows where possible
-	return plan_for(p, lo, pl);
+	return plan_for(p, lo, flat, pl);
+}
+
+static bool skr_nodes_plan(const RenderParams &p, NodePlan &pl)
+{
+	if(nodes_flat_wanted(p))
+	{ // flat only in one piece (SKR_FLAT=1: wherever it fits at all): in bands the persistent kernel is the better schedule
+		const uint32_t all = (uint32_t) ((p.width + 15) / 16) * ((p.out_rows + 15) / 16);
+		if(plan_bands(p, true, pl) && (p.sw.flat > 0 || pl.band_nblk >= all)) return true;
+	}
+	return plan_bands(p, false, pl);
 }
 
 // The node pipeline covers --gillum trees of any depth >= 2 on sphere scenes (<= 256 children per node, < 65536 spheres).
@@ -800,6 +889,13 @@ bool skr_nodes_selected(const RenderParams &p)
 	// triangle meshes at depth 2..3 stay on the parent-queue pipeline (their rounds are long and few: DESIGN.md 5.0);
 	// beyond depth 3 this is the only pipeline
 	return p.n_tris <= 64 || p.max_depth > 3;
+}
+
+// the schedule this launch takes: the flat one (small launches) or the persistent leaf kernel
+bool skr_nodes_flat(const RenderParams &p)
+{
+	NodePlan pl;
+	return skr_nodes_plan(p, pl) && pl.flat;
 }
 
 size_t skr_nodes_scratch_bytes(const RenderParams &p)
@@ -845,7 +941,8 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 	const size_t lds_scene = ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 32;
 	const size_t lds_leaf = skr_nodes_lds_bytes(p);
 	const bool tris = p.n_tris > 0;
-	const int D = p.max_depth, last = D - 2; // record levels 1 .. last; the leaf kernel works on level `last`
+	const bool flat = pl.flat;
+	const int D = p.max_depth, last = flat ? D - 1 : D - 2; // record levels 1 .. last; the leaf kernel (flat: skr_shade_leaf_kernel) works on level `last`
 	const uint32_t blocks_x = (uint32_t) (p.width + 15) / 16, blocks = blocks_x * ((p.out_rows + 15) / 16);
 	p.node_layout = 1;
 	p.blocks_x = blocks_x;
@@ -866,7 +963,7 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 			p.nd_dst_stride = pl.stride0;
 			e = skr_launch_primary(p, dim3(p.band_nblk), lds_scene, stream);
 			if(e != hipSuccess) return e;
-			if(D == 2)
+			if(D == 2 && !flat)
 			{ // the level-0 nodes' children are the leaves
 				p.nd_src = nodes(0);
 				p.nd_src_stride = pl.stride0;
@@ -890,12 +987,13 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 				p.rc_ctr = lvl_ctr(L);
 				p.ix16 = reinterpret_cast<uint16_t *>(base + pl.off_ix[L - 1]);
 				p.ixh = reinterpret_cast<uint2 *>(base + pl.off_ixh[L - 1]);
-				const unsigned grid_t = (unsigned) ((pl.nodes_max[L - 1] * (uint64_t) ((p.num_path_traces + 1) >> 1) + 255) / 256);
+				const uint64_t wg_t = (pl.nodes_max[L - 1] * (uint64_t) ((p.num_path_traces + 1) >> 1) + 255) / 256;
+				const unsigned grid_t = (unsigned) (wg_t < SKR_TRACE_GRID_MAX ? wg_t : SKR_TRACE_GRID_MAX);
+				if(flat && L == last && timed && hook->start) (void) hipEventRecord(hook->start, stream); // (flat: the last level's trace + shading are the dominant pair)
 				if(tris) hipLaunchKernelGGL(skr_trace_kernel<true>, dim3(grid_t), dim3(256), lds_scene, stream, p);
 				else hipLaunchKernelGGL(skr_trace_kernel<false>, dim3(grid_t), dim3(256), lds_scene, stream, p);
 				if(L < last)
 				{ // its records become the nodes of level L
-					hipLaunchKernelGGL(skr_prefix_kernel, dim3(1), dim3(64), 0, stream, p);
 					p.nd_dst = nodes(L);
 					p.nd_dst_stride = 4;
 					const unsigned grid_a = SKR_P1_REGIONS * ((pl.cap[L] + 255u) / 256u);
@@ -903,12 +1001,22 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 					else hipLaunchKernelGGL(skr_activate_kernel<false>, dim3(grid_a), dim3(256), lds_scene, stream, p);
 				}
 			}
-			// leaf kernel: the records of the last level (their parents: level last - 1), results into res[last]
 			p.res_out = reinterpret_cast<float *>(base + pl.off_res[last]);
-			if(timed && hook->start) (void) hipEventRecord(hook->start, stream);
-			e = launch_leaf2<false>(p, lds_leaf, stream);
-			if(timed && hook->stop) (void) hipEventRecord(hook->stop, stream);
-			if(e != hipSuccess) return e;
+			if(flat)
+			{ // the records of the last level are the leaves' hits: shaded one per lane, results into res[last]
+				const uint64_t wg = (pl.nodes_max[last] + 255) / 256;
+				const unsigned grid_s = (unsigned) (wg < 16384 ? wg : 16384);
+				if(tris) hipLaunchKernelGGL(skr_shade_leaf_kernel<true>, dim3(grid_s), dim3(256), lds_scene, stream, p);
+				else hipLaunchKernelGGL(skr_shade_leaf_kernel<false>, dim3(grid_s), dim3(256), lds_scene, stream, p);
+				if(timed && hook->stop) (void) hipEventRecord(hook->stop, stream);
+			}
+			else
+			{ // leaf kernel: the records of the last level (their parents: level last - 1), results into res[last]
+				if(timed && hook->start) (void) hipEventRecord(hook->start, stream);
+				e = launch_leaf2<false>(p, lds_leaf, stream);
+				if(timed && hook->stop) (void) hipEventRecord(hook->stop, stream);
+				if(e != hipSuccess) return e;
+			}
 			for(int L = last - 1; L >= 0; L--)
 			{ // sums, deepest level first
 				p.nd_src = nodes(L);

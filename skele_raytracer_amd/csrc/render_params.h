@@ -29,6 +29,7 @@ struct SkrSwitches {
 	int32_t tile = 0;                 // SKR_TILE = 64 | 32 | 16: pixels per wave tile of the megakernel (0 = choose)
 	int32_t no_cones = 0, no_cull = 0; // SKR_NO_CONES, SKR_NO_CULL: triangle-walk culling off
 	int32_t budget_mb = 0;            // SKR_LEVELS_BUDGET_MB: scratch budget of the level pipelines (0 = default)
+	int32_t flat = 0;                 // SKR_FLAT = 1 | 0: the node pipeline's flat schedule forced on (+1) / off (-1); unset: by launch size
 };
 
 struct RenderParams {

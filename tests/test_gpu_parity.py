@@ -91,8 +91,15 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("schedule", ["auto", "persistent"])
 @pytest.mark.parametrize("name,scn,w,h,kw", CASES, ids=[c[0] for c in CASES])
-def test_gpu_matches_oracle_bit_for_bit(gpu, oracle, name, scn, w, h, kw):
+def test_gpu_matches_oracle_bit_for_bit(gpu, oracle, monkeypatch, name, scn, w, h, kw, schedule):
+    # the node pipeline has two schedules: frames this small take the flat one by themselves; SKR_FLAT=0 puts
+    # the same cases through the persistent leaf kernel, which full-size frames use
+    if schedule == "persistent":
+        if kw.get("gillum") is None:
+            pytest.skip("no --gillum tree: the node pipeline is not involved")
+        monkeypatch.setenv("SKR_FLAT", "0")
     g_rgb, g_f, cnt = gpu_render(scn, w, h, **kw)
     o_rgb, o_f, st = oracle.render(scene_path(scn), w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, **kw)
     compare(g_rgb, g_f, o_rgb, o_f, name)
@@ -307,7 +314,7 @@ def test_all_kernel_variants_agree(gpu, monkeypatch):
     produce the same bits and the same ray counts."""
     w, h = 176, 99
     r = renderer("spheres2.scn")
-    knobs = ("SKR_PIPELINE", "SKR_KERNEL", "SKR_OCC", "SKR_TILE", "SKR_LEVELS_BUDGET_MB")
+    knobs = ("SKR_PIPELINE", "SKR_KERNEL", "SKR_OCC", "SKR_TILE", "SKR_LEVELS_BUDGET_MB", "SKR_FLAT")
 
     def run(opt, env):
         for k in knobs:
@@ -321,9 +328,11 @@ def test_all_kernel_variants_agree(gpu, monkeypatch):
 
     opt = skr.Options(w, h, gillum=8, shadow=True, seed=31)
     base = run(opt, {})
-    assert base[3] == "node_levels_v5"
+    assert base[3] == "node_levels_v5_flat"  # (a frame this small: every level a plain grid)
     seen = {base[3]}
-    for env in ({"SKR_LEVELS_BUDGET_MB": "2"},  # 2 MiB of tables: bands of a few 16x16 blocks
+    for env in ({"SKR_FLAT": "0"},              # the persistent leaf kernel, as on a full-size frame
+                {"SKR_LEVELS_BUDGET_MB": "2"},  # 2 MiB of tables: bands of a few 16x16 blocks (the persistent schedule: flat runs in one piece only)
+                {"SKR_FLAT": "1", "SKR_LEVELS_BUDGET_MB": "8"},  # flat forced into bands
                 {"SKR_PIPELINE": "levels"}, {"SKR_PIPELINE": "levels", "SKR_LEVELS_BUDGET_MB": "1"},
                 {"SKR_PIPELINE": "queue"}, {"SKR_PIPELINE": "queue", "SKR_OCC": "2"}, {"SKR_PIPELINE": "queue", "SKR_OCC": "3"},
                 {"SKR_PIPELINE": "mega"}, {"SKR_PIPELINE": "mega", "SKR_TILE": "64"}, {"SKR_PIPELINE": "mega", "SKR_TILE": "16"},
@@ -332,12 +341,12 @@ def test_all_kernel_variants_agree(gpu, monkeypatch):
         seen.add(got[3])
         assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
         assert got[2] == base[2], env
-    assert seen == {"node_levels_v5", "level_queues_v4", "parent_queue_v3", "wave_streaming_v2", "lane_per_pixel_dfs_v1f"}
+    assert seen == {"node_levels_v5_flat", "node_levels_v5", "level_queues_v4", "parent_queue_v3", "wave_streaming_v2", "lane_per_pixel_dfs_v1f"}
     # depth 2 (the leaf kernel works on the primary hits) and depth 4 (one activate + trace level in between)
-    for opt2, others in ((skr.Options(w, h, gillum=8, shadow=True, depth=2, seed=31), ({"SKR_PIPELINE": "queue"}, {"SKR_PIPELINE": "mega"})),
-                         (skr.Options(96, 54, gillum=3, shadow=True, depth=4, seed=31), ({"SKR_PIPELINE": "mega", "SKR_KERNEL": "v1"}, {"SKR_LEVELS_BUDGET_MB": "8"}))):
+    for opt2, others in ((skr.Options(w, h, gillum=8, shadow=True, depth=2, seed=31), ({"SKR_PIPELINE": "queue"}, {"SKR_PIPELINE": "mega"}, {"SKR_FLAT": "0"})),
+                         (skr.Options(96, 54, gillum=3, shadow=True, depth=4, seed=31), ({"SKR_PIPELINE": "mega", "SKR_KERNEL": "v1"}, {"SKR_LEVELS_BUDGET_MB": "8"}, {"SKR_FLAT": "0"}))):
         b2 = run(opt2, {})
-        assert b2[3] == "node_levels_v5"
+        assert b2[3] == "node_levels_v5_flat"
         for env in others:
             got = run(opt2, env)
             assert np.array_equal(got[0], b2[0]) and np.array_equal(got[1], b2[1]) and got[2] == b2[2], env
@@ -362,7 +371,7 @@ def test_node_pipeline_in_bands_on_triangles_and_deep(gpu, oracle, monkeypatch):
         r.counters(reset=True)
         rgb, rgbf = r.render(skr.Options(w, h, **kw), want_float=True)
         gpu.cuda.synchronize()
-        assert r.kernel_variant() == "node_levels_v5", (scn, kw, env)
+        assert r.kernel_variant() in ("node_levels_v5", "node_levels_v5_flat"), (scn, kw, env)
         o_rgb, o_f, st = oracle.render(scene_path(scn), w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, **kw)
         compare(rgb.cpu().numpy(), rgbf.cpu().numpy(), o_rgb, o_f, "%s %s %s" % (scn, kw, env))
         cnt = r.counters()

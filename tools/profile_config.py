@@ -9,6 +9,8 @@ CONFIGS = {
     "2": ("spheres2.scn", 1920, 1080, dict(jsample=5, shadow=True, seed=9)),
     "3": ("spheres2.scn", 1920, 1080, dict(gillum=16, shadow=True, seed=20261004)),
     "4": ("dragon.scn", 1920, 1080, dict(gillum=16)),
+    "d4": ("spheres2.scn", 1920, 1080, dict(gillum=4, depth=4, shadow=True, seed=3)),   # every kernel of the node pipeline, incl. activate / prefix
+    "d3n4": ("spheres2.scn", 1920, 1080, dict(gillum=4, depth=3, shadow=True, seed=3)),
 }
 scn, w, h, kw = CONFIGS[sys.argv[1]]
 r = skr.Renderer(skr.parse_scene(os.path.join(ROOT, "tests/golden/scenes", scn)))
