@@ -220,6 +220,13 @@ void skr_comm_destroy(skr_comm *c);
 /* Asynchronous on `stream`: this rank's tiles, the all-gather, rank 0's de-interleave.  *d_frame: rank 0's finished
  * frame (device memory owned by c; NULL on the other ranks) once the stream has drained. */
 int skr_comm_render_frame(skr_comm *c, const skr_options *opt, uint32_t tile_rows, uint8_t **d_frame, void *stream);
+/* The frame step with its collective off the render stream (throughput of a run of frames): frame f's all-gather and
+ * de-interleave run on a stream the communicator owns while `stream` renders frame f + 1 into the other of two buffer sets.
+ * *d_prev_frame (rank 0; NULL elsewhere and on the first call): the PREVIOUS call's frame, complete in `stream` order after
+ * this call (pass d_prev_frame = NULL not to look at it: one stream wait less per frame).  skr_comm_flush ends the run: `stream` waits for the last collective, *d_frame = the last frame.  Every frame is
+ * the one skr_comm_render_frame would have produced. */
+int skr_comm_render_frame_async(skr_comm *c, const skr_options *opt, uint32_t tile_rows, uint8_t **d_prev_frame, void *stream);
+int skr_comm_flush(skr_comm *c, uint8_t **d_frame, void *stream);
 /* Rank 0: waits for `stream` and copies that frame to host memory (W*H*3 bytes). */
 int skr_comm_frame_to_host(skr_comm *c, uint8_t *h_rgb, void *stream);
 /* The partition itself (host logic, no GPU): padded tiles per rank, and the de-interleave of a rank-major gathered

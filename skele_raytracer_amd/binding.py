@@ -14,7 +14,7 @@ EXPORTED_SYMBOLS = [
     "skr_renderer_read_counters", "skr_renderer_read_work", "skr_renderer_reload_switches", "skr_renderer_kernel_timing", "skr_renderer_kernel_ms", "skr_renderer_last_parent_count", "skr_renderer_last_level1_count", "skr_render_frame_host", "skr_render_progressive_host", "skr_accumulate", "skr_resolve_accumulated", "skr_write_png", "skr_write_pfm", "skr_write_ppm", "skr_last_error",
     "skr_kernel_variant", "skr_debug_eval",
     "skr_rccl_available", "skr_multi_create", "skr_multi_destroy", "skr_multi_device_count", "skr_multi_renderer", "skr_multi_render_frame",
-    "skr_multi_render_frame_host", "skr_comm_unique_id", "skr_comm_create", "skr_comm_destroy", "skr_comm_render_frame", "skr_comm_frame_to_host",
+    "skr_multi_render_frame_host", "skr_comm_unique_id", "skr_comm_create", "skr_comm_destroy", "skr_comm_render_frame", "skr_comm_render_frame_async", "skr_comm_flush", "skr_comm_frame_to_host",
     "skr_shard_tiles_per_rank", "skr_shard_deinterleave_host",
 ]
 
@@ -118,6 +118,8 @@ def lib():
     L.skr_comm_destroy.restype = None
     L.skr_comm_render_frame.argtypes = [vp, C.POINTER(COptions), C.c_uint32, C.POINTER(vp), vp]
     L.skr_comm_frame_to_host.argtypes = [vp, vp, vp]
+    L.skr_comm_render_frame_async.argtypes = [vp, C.POINTER(COptions), C.c_uint32, C.POINTER(vp), vp]
+    L.skr_comm_flush.argtypes = [vp, C.POINTER(vp), vp]
     L.skr_shard_tiles_per_rank.argtypes = [C.c_int32, C.c_uint32, C.c_uint32]
     L.skr_shard_tiles_per_rank.restype = C.c_uint32
     L.skr_shard_deinterleave_host.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32]
@@ -396,6 +398,20 @@ class Comm:
         self.renderer._sync_switches()
         d = C.c_void_p()
         _check(lib().skr_comm_render_frame(self.h, C.byref(opt.c), tile_rows, C.byref(d), stream), "skr_comm_render_frame")
+        return d.value
+
+    def render_frame_async(self, opt, tile_rows, stream=None, want_previous=True):
+        """Enqueue one frame with its collective on the communicator's own stream (include/skr.h skr_comm_render_frame_async);
+        returns the device address of the PREVIOUS call's frame (rank 0; None on the first call, on the other ranks, and when not asked for)."""
+        self.renderer._sync_switches()
+        d = C.c_void_p()
+        _check(lib().skr_comm_render_frame_async(self.h, C.byref(opt.c), tile_rows, C.byref(d) if want_previous else None, stream), "skr_comm_render_frame_async")
+        return d.value
+
+    def flush(self, stream=None):
+        """Ends a run of render_frame_async calls: `stream` waits for the last collective; returns the last frame's address (rank 0)."""
+        d = C.c_void_p()
+        _check(lib().skr_comm_flush(self.h, C.byref(d), stream), "skr_comm_flush")
         return d.value
 
     def frame_to_host(self, opt, stream=None):

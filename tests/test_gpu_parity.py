@@ -666,6 +666,45 @@ def test_multi_rank_paths_rehearsed_on_one_gpu(gpu, tmp_path, world):
     assert "cpu_baseline" not in out and out["roofline"]["kernel_ms"] > 0
 
 
+def test_pipelined_frame_step_returns_every_frame(gpu):
+    """skr_comm_render_frame_async: the collective and the de-interleave of frame f on the communicator's own stream while the
+    caller's stream renders frame f + 1.  Six frames with six seeds (and a change of geometry in between): every frame handed back —
+    one call late, the last one by skr_comm_flush — must be the frame a plain render of that seed gives."""
+    r = renderer("spheres2.scn")
+    st = gpu.cuda.current_stream()
+
+    def frame_at(addr, w, h):  # a device address libskr owns -> numpy, in stream order
+        buf = gpu.empty((h, w, 3), dtype=gpu.uint8, device="cuda")
+        from skele_raytracer_amd.binding import C
+        lib = C.CDLL("libamdhip64.so")
+        lib.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        assert lib.hipMemcpyAsync(buf.data_ptr(), addr, w * h * 3, 3, st.cuda_stream) == 0  # 3 = device to device
+        st.synchronize()
+        return buf.cpu().numpy()
+
+    for with_rccl in (False, True):
+        c = binding.Comm(r, 0, 1, binding.comm_unique_id() if with_rccl else None)
+        shapes = [(333, 187, 8)] * 3 + [(200, 113, 16)] * 3
+        got, want = [], []
+        for k, (w, h, tile_rows) in enumerate(shapes):
+            opt = skr.Options(w, h, gillum=4, shadow=True, seed=100 + k)
+            prev = c.render_frame_async(opt, tile_rows, st.cuda_stream)
+            if k == 0:
+                assert prev is None
+            else:
+                pw, ph, _ = shapes[k - 1]
+                got.append(frame_at(prev, pw, ph))
+        last = c.flush(st.cuda_stream)
+        got.append(frame_at(last, shapes[-1][0], shapes[-1][1]))
+        c.close()
+        for k, (w, h, _) in enumerate(shapes):
+            f, _ = r.render(skr.Options(w, h, gillum=4, shadow=True, seed=100 + k))
+            want.append(f.cpu().numpy())
+        assert len(got) == len(want) == 6
+        for k in range(6):
+            assert np.array_equal(got[k], want[k]), (with_rccl, k)
+
+
 def test_native_frame_step_on_one_gpu(gpu, tmp_path):
     """The multi-GPU frame step that lives inside libskr (include/skr.h "multi-GPU": tiles into the gather buffer, ONE
     ncclAllGather, de-interleave kernel), as far as a one-GPU box can run it: a world of one with a real RCCL communicator
