@@ -201,6 +201,21 @@ def main():
         else:
             sharder.step(lambda buf: r.render_tiles_into(opt, TILE_ROWS, rank, world, buf.data_ptr(), None, stream.cuda_stream))
 
+    if pipelined:
+        # one pipelined frame before anything is timed: a rank on which it cannot be set up takes every rank back to the serial step
+        ok_async = 1
+        try:
+            comm.render_frame_async(opt, TILE_ROWS, stream.cuda_stream, want_previous=False)
+            comm.flush(stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+        except skr.SkrError as e:
+            ok_async, native_note = 0, "pipelined frame step unavailable (%s): serial skr_comm_render_frame used" % str(e)[:160]
+        if world > 1:
+            t_ok = torch.tensor([ok_async], device=dev)
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            ok_async = int(t_ok.item())
+        pipelined = bool(ok_async)
+
     def sync():
         if pipelined:
             comm.flush(stream.cuda_stream)  # the last frame's collective is part of the timed region
