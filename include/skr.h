@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SKR_ABI_VERSION 3 /* 3: skr_options grew by shade_triangles and progressive_passes (48 bytes); 2: multi-GPU entry points, skr_scene_info.n_directional_lights */
+#define SKR_ABI_VERSION 3 /* 3: skr_options grew by shade_triangles, progressive_passes and legacy_reflect (56 bytes); 2: multi-GPU entry points, skr_scene_info.n_directional_lights */
 
 typedef enum {
 	SKR_OK = 0,
@@ -67,6 +67,17 @@ typedef struct {
 	                           * for, headless).  K > 1: every render entry point traces K whole frames under the seeds seed, seed+1, ...,
 	                           * seed+K-1, sums them in binary32 in that order, divides by (float) K once and quantises the mean like
 	                           * a single frame (main.cpp:205).  K <= 1 is the single frame, bit for bit. */
+	int32_t legacy_reflect;   /* new, default 0 (`raytracer --legacy-reflect`).  1 = the code behind the early
+	                           * `return total_colour;` of raytrace.h:44 runs: the Fresnel term fr (blinn_phong.h:156-184) and, where the
+	                           * material's specular colour is not (0,0,0), for every light (point lights first) a refraction ray
+	                           * (:143-153; `refraction_colour = fr * shade(...)`: the last light's stays) and a reflection ray (:137-140:
+	                           * the LIGHT direction mirrored at the normal; `+= (1 - fr) * specular * shade(...)`), both from the hit point
+	                           * itself with depth - 1, added to the direct term as raytrace.h:102 does.  The index of refraction is the
+	                           * 14th number of the `material` line (skr_scene_set_sphere_ior for scenes from arrays; default 1).
+	                           * Children of the counter RNG's tree: arity N + 2 L (L lights); child N + 2 l = refraction of light l,
+	                           * N + 2 l + 1 = its reflection.  Unreachable at HEAD, so no output of the reference's code pins it; the
+	                           * reference's README pictures (made when it ran) are the visual check (tests/test_legacy_reflect.py).
+	                           * Lane-per-pixel kernel, --depth <= 6; not together with shade_triangles. */
 } skr_options;
 
 typedef struct {
@@ -119,6 +130,10 @@ int skr_scene_get_culling(const skr_scene *scene, int32_t level, int32_t *chunk_
  * phong power — what the `material` line in force gives a `triangle` line in a .scn file (scene.cpp:110-137; the reference
  * keeps no material for a triangle, shapes.h:26).  Read by skr_options.shade_triangles only; default: material.h:9-17's. */
 int skr_scene_set_triangle_materials(skr_scene *scene, const float *materials);
+
+/* Index of refraction of every sphere of a scene built from arrays, ior[n_spheres] (material.h:16; the 14th number of a
+ * `material` line, scene.cpp:110-137).  Read by skr_options.legacy_reflect only; default 1. */
+int skr_scene_set_sphere_ior(skr_scene *scene, const float *ior);
 
 /* ---- options: replaces Options' in-class defaults (utils.h:28-33) ---- */
 void skr_options_default(skr_options *opt);

@@ -57,7 +57,7 @@ class Options(C.Structure):
                 ("monte_carlo", C.c_int32), ("num_path_traces", C.c_int32), ("grid_size", C.c_int32),
                 ("max_depth", C.c_int32), ("use_shadows", C.c_int32), ("rng_mode", C.c_int32),
                 ("math_mode", C.c_int32), ("seed", C.c_uint64), ("y0", C.c_int32), ("y1", C.c_int32),
-                ("threads", C.c_int32), ("shade_triangles", C.c_int32)]
+                ("threads", C.c_int32), ("shade_triangles", C.c_int32), ("legacy_reflect", C.c_int32)]
 
 
 _lib = None
@@ -134,13 +134,13 @@ def host_cores():
 
 
 def render(scene, width, height, *, fov=60.0, gillum=None, jsample=0, depth=3, shadow=False,
-           rng=RNG_COUNTER, math=MATH_SHARED, seed=1, y0=0, y1=None, threads=None, want_float=False, strict=False, shade_triangles=False):
+           rng=RNG_COUNTER, math=MATH_SHARED, seed=1, y0=0, y1=None, threads=None, want_float=False, strict=False, shade_triangles=False, legacy_reflect=False):
     """Returns (rgb uint8 [rows,W,3], float image or None, stats uint64[5])."""
     if isinstance(scene, (str, os.PathLike)):
         scene = OracleScene(scene, strict=strict)
     y1 = height if y1 is None else y1
     o = Options(width, height, fov, 0 if gillum is None else 1, 1 if gillum is None else gillum, jsample,
-                depth, int(bool(shadow)), rng, math, seed, y0, y1, threads or host_cores(), int(bool(shade_triangles)))
+                depth, int(bool(shadow)), rng, math, seed, y0, y1, threads or host_cores(), int(bool(shade_triangles)), int(bool(legacy_reflect)))
     rows = y1 - y0
     rgb = np.zeros((rows, width, 3), np.uint8)
     rgbf = np.zeros((rows, width, 3), np.float32) if want_float else None

@@ -383,6 +383,74 @@ static v3 direct_illumination(ctx_t *cx, const sko_sphere *sp, v3 P, v3 N)
 static v3 shade_from(ctx_t *cx, v3 o, v3 d, int depth, uint32_t node, int from_triangle);
 static inline v3 shade(ctx_t *cx, v3 o, v3 d, int depth, uint32_t node) { return shade_from(cx, o, d, depth, node, -1); }
 
+/* children per node of the counter RNG's tree: the --gillum rays, then (--legacy-reflect) a refraction and a reflection ray per light */
+static inline uint32_t node_arity(const ctx_t *cx)
+{
+	uint32_t a = (uint32_t) cx->op->num_path_traces;
+	if(cx->op->legacy_reflect) a += 2u * (uint32_t) (cx->sc->n_point_lights + cx->sc->n_directional_lights);
+	return a;
+}
+
+/* utils.h:132-146 clamp(a, b, input) */
+static inline float clampf(float a, float b, float x) { return x < a ? a : (x > b ? b : x); }
+
+/* blinn_phong.h:156-184 fresnel().  `sqrt` is unqualified there: ::sqrt(double) on a float argument, its double result meeting floats
+ * (sint: float * double -> double, narrowed by the assignment; cos_theta: narrowed).  powf(x, 2.0f) == x * x.  Everything else binary32. */
+static float legacy_fresnel(v3 dir, v3 N, float mat_ior)
+{
+	float cos_internal = clampf(-1.0f, 1.0f, vdot(dir, N));
+	float et = 1.0f, ior = mat_ior;
+	if(cos_internal > 0) { float t = et; et = ior; ior = t; }
+	float sint = (float) ((double) (et / ior) * sqrt((double) max0(1.0f - cos_internal * cos_internal)));
+	if(sint >= 1.0f) return 1.0f;
+	float cos_theta = (float) sqrt((double) max0(1 - sint * sint));
+	cos_internal = fabsf(cos_internal);
+	float Rs = ((ior * cos_internal) - (et * cos_theta)) / ((ior * cos_internal) + (et * cos_theta));
+	float Rp = ((et * cos_internal) - (ior * cos_theta)) / ((ior * cos_internal) + (et * cos_theta));
+	return (Rs * Rs + Rp * Rp) / 2.0f;
+}
+
+/* blinn_phong.h:143-153 refraction() */
+static v3 legacy_refraction(v3 dir, v3 N, float ior)
+{
+	float dn = vdot(dir, N);
+	float k = 1.0f - (ior * ior) * (1.0f - dn * dn);
+	if(k < 0.0f) return V(0, 0, 0);
+	return vsub(vscale(dir, ior), vscale(N, ior * dn + sqrtf(k)));
+}
+
+/* blinn_phong.h:137-140 reflect_direction(): glm::normalize(L - 2.0f * dot(L, N) * N) */
+static v3 legacy_reflect_direction(v3 L, v3 N)
+{
+	return vnormalize(vsub(L, vscale(N, 2.0f * vdot(L, N))));
+}
+
+/* raytrace.h:45-103, the part of direct_illumination() behind its early return */
+static v3 legacy_terms(ctx_t *cx, v3 total_colour, v3 ray_dir, const sko_sphere *sp, v3 P, v3 N, int depth, uint32_t node)
+{
+	const sko_scene *sc = cx->sc;
+	float fr = legacy_fresnel(ray_dir, N, sp->ior);
+	v3 refraction_colour = V(0, 0, 0), reflection_colour = V(0, 0, 0);
+	if((sp->specular.x != 0.0f || sp->specular.y != 0.0f || sp->specular.z != 0.0f) && depth > 0)
+	{
+		const uint32_t A = node_arity(cx), base = node * A + (uint32_t) cx->op->num_path_traces + 1u;
+		const int nl = sc->n_point_lights + sc->n_directional_lights;
+		for(int i = 0; i < nl; i++)
+		{ /* :54-77 the point lights, :80-99 the directional ones: the same statements */
+			v3 L = i < sc->n_point_lights ? vnormalize(vsub(sc->point_lights[i].position, P)) : vnormalize(sc->directional_lights[i - sc->n_point_lights].direction);
+			if(fr < 1)
+			{
+				v3 rd = legacy_refraction(ray_dir, N, sp->ior);
+				refraction_colour = vscale(shade_from(cx, P, rd, depth - 1, base + 2u * (uint32_t) i, -1), fr); /* (=, not +=) */
+			}
+			v3 md = legacy_reflect_direction(L, N);
+			v3 c = shade_from(cx, P, md, depth - 1, base + 2u * (uint32_t) i + 1u, -1);
+			reflection_colour = vadd(reflection_colour, vmul(vscale(sp->specular, 1 - fr), c)); /* (1 - fr) * specular * shade(...) */
+		}
+	}
+	return vadd(vadd(total_colour, refraction_colour), reflection_colour); /* :102, in that order */
+}
+
 /* raytrace.h:22-30 uniform_sample_hemi */
 static inline v3 sample_hemi(const ctx_t *cx, float r1, float r2)
 {
@@ -419,7 +487,7 @@ static v3 global_illumination(ctx_t *cx, v3 P, v3 N, int depth, uint32_t node, i
 			v3 w = V(s.x * nb.x + s.y * N.x + s.z * nt.x,
 					 s.x * nb.y + s.y * N.y + s.z * nb.y,
 					 s.x * nb.z + s.y * N.z + s.z * nb.z);
-			child = shade_from(cx, vadds(P, 0.00001f), w, depth - 1, node * (uint32_t) n_rays + (uint32_t) i + 1u, from_triangle);
+			child = shade_from(cx, vadds(P, 0.00001f), w, depth - 1, node * node_arity(cx) + (uint32_t) i + 1u, from_triangle);
 		}
 		/* depth-1 <= 0: shade() returns (0,0,0) at once (raytrace.h:142-145); r1*0/pdf == 0 for any finite r1 */
 		total = vadd(total, vdivs(vscale(child, r1), pdf));
@@ -495,6 +563,7 @@ static v3 shade_from(ctx_t *cx, v3 o, v3 d, int depth, uint32_t node, int from_t
 		v3 N = vnormalize(vsub(P, sp->center));
 		cx->n_hits++;
 		v3 direct = direct_illumination(cx, sp, P, N);
+		if(cx->op->legacy_reflect) direct = legacy_terms(cx, direct, d, sp, P, N, depth, node);
 		if(cx->op->monte_carlo)
 		{
 			v3 indirect = global_illumination(cx, P, N, depth, node, -1);

@@ -81,6 +81,13 @@ typedef struct {
 	 * normalize(cross(v1-v0, v2-v0)) turned against the ray, shadow rays against spheres only (utils.h:42-76), --gillum children
 	 * from P + 1e-5 with the basis of utils.h:148-165. */
 	int32_t shade_triangles;
+	/* --legacy-reflect: the code behind the early `return total_colour;` of raytrace.h:44 runs — the Fresnel term
+	 * (blinn_phong.h:156-184), and for every light one refraction ray (:143-153, `=`: the last light's stays) and one reflection ray
+	 * (:137-140: the LIGHT direction mirrored at the normal) from the hit point itself, each shade(depth - 1), added to the direct
+	 * term (raytrace.h:45-103).  UNREACHABLE at HEAD: no output of the reference covers it.  What the C++ of those lines does is
+	 * restated literally (unqualified sqrt = binary64, powf(x, 2) = x*x, abs = fabsf); the children's nodes of the counter RNG:
+	 * arity A = N + 2 (lights), child N + 2 l = refraction of light l, N + 2 l + 1 = its reflection (point lights first). */
+	int32_t legacy_reflect;
 } sko_options;
 
 /* stats[0]=radiance rays (shade() calls with depth>0), [1]=sphere hits shaded,

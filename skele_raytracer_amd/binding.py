@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # every symbol include/skr.h declares (tests/test_abi.py checks the library exports them)
 EXPORTED_SYMBOLS = [
-    "skr_scene_create_from_scn", "skr_scene_create_from_scn_ex", "skr_scene_create_from_arrays", "skr_scene_set_triangle_materials", "skr_scene_destroy", "skr_scene_get_info",
+    "skr_scene_create_from_scn", "skr_scene_create_from_scn_ex", "skr_scene_create_from_arrays", "skr_scene_set_triangle_materials", "skr_scene_set_sphere_ior", "skr_scene_destroy", "skr_scene_get_info",
     "skr_scene_get_arrays", "skr_scene_get_culling", "skr_options_default", "skr_radiance_ray_count", "skr_device_count",
     "skr_renderer_create", "skr_renderer_destroy", "skr_render_tiles", "skr_tile_count", "skr_render_rows",
     "skr_renderer_read_counters", "skr_renderer_read_work", "skr_renderer_reload_switches", "skr_renderer_kernel_timing", "skr_renderer_kernel_ms", "skr_renderer_last_parent_count", "skr_renderer_last_level1_count", "skr_render_frame_host", "skr_render_progressive_host", "skr_accumulate", "skr_resolve_accumulated", "skr_write_png", "skr_write_pfm", "skr_write_ppm", "skr_last_error",
@@ -27,7 +27,7 @@ class COptions(C.Structure):
     # struct skr_options == reference struct Options (utils.h:26-34) + width/height/use_shadows
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fov", C.c_float), ("monte_carlo", C.c_int32),
                 ("num_path_traces", C.c_int32), ("grid_size", C.c_int32), ("max_depth", C.c_int32),
-                ("use_shadows", C.c_int32), ("seed", C.c_uint64), ("shade_triangles", C.c_int32), ("progressive_passes", C.c_int32)]
+                ("use_shadows", C.c_int32), ("seed", C.c_uint64), ("shade_triangles", C.c_int32), ("progressive_passes", C.c_int32), ("legacy_reflect", C.c_int32)]
 
 
 # include/skr.h skr_progress_fn: (user, passes_done, passes, h_rgb, h_rgbf) -> non-zero stops the render
@@ -69,6 +69,7 @@ def lib():
     L.skr_scene_create_from_scn_ex.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(vp)]
     L.skr_scene_create_from_arrays.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, C.c_int32, vp, vp, vp, C.POINTER(vp)]
     L.skr_scene_set_triangle_materials.argtypes = [vp, vp]
+    L.skr_scene_set_sphere_ior.argtypes = [vp, vp]
     L.skr_scene_destroy.argtypes = [vp]
     L.skr_scene_destroy.restype = None
     L.skr_scene_get_info.argtypes = [vp, C.POINTER(CSceneInfo)]
@@ -136,7 +137,7 @@ class Options:
     """Reference struct Options (utils.h:26-34) with the reference's defaults, plus the
     width/height/use_shadows main() folds in (main.cpp:393-396) and the RNG seed."""
 
-    def __init__(self, width=1920, height=1080, fov=60.0, gillum=None, jsample=0, depth=3, shadow=False, seed=1, shade_triangles=False, progressive=1):
+    def __init__(self, width=1920, height=1080, fov=60.0, gillum=None, jsample=0, depth=3, shadow=False, seed=1, shade_triangles=False, progressive=1, legacy_reflect=False):
         c = COptions()
         lib().skr_options_default(C.byref(c))
         c.width, c.height, c.fov = width, height, fov
@@ -145,6 +146,7 @@ class Options:
         c.grid_size, c.max_depth, c.use_shadows, c.seed = jsample, depth, int(bool(shadow)), seed
         c.shade_triangles = int(bool(shade_triangles))  # --shade-triangles (include/skr.h): triangles as surfaces, not black holes
         c.progressive_passes = max(1, int(progressive))  # --progressive K: the mean of K frames under the seeds seed .. seed+K-1
+        c.legacy_reflect = int(bool(legacy_reflect))  # --legacy-reflect (include/skr.h): the reflection / refraction code behind raytrace.h:44's early return
         self.c = c
 
     @property
@@ -201,7 +203,7 @@ class Scene:
         return cs.value, tris, sph, links, ch
 
     @staticmethod
-    def from_arrays(spheres, triangles, point_lights, camera, background=(0, 0, 0), ambient=(0, 0, 0), triangle_materials=None):
+    def from_arrays(spheres, triangles, point_lights, camera, background=(0, 0, 0), ambient=(0, 0, 0), triangle_materials=None, sphere_ior=None):
         s = np.ascontiguousarray(spheres, np.float32).reshape(-1, 14)
         t = np.ascontiguousarray(triangles, np.float32).reshape(-1, 9)
         l = np.ascontiguousarray(point_lights, np.float32).reshape(-1, 6)
@@ -216,6 +218,9 @@ class Scene:
         if triangle_materials is not None:  # [n_triangles][10] ambient diffuse specular power (--shade-triangles)
             m = np.ascontiguousarray(triangle_materials, np.float32).reshape(len(t), 10)
             _check(lib().skr_scene_set_triangle_materials(sc.h, m.ctypes.data), "skr_scene_set_triangle_materials")
+        if sphere_ior is not None:  # [n_spheres] (--legacy-reflect)
+            q = np.ascontiguousarray(sphere_ior, np.float32).reshape(len(s))
+            _check(lib().skr_scene_set_sphere_ior(sc.h, q.ctypes.data), "skr_scene_set_sphere_ior")
         return sc
 
 

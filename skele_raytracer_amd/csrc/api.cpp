@@ -281,21 +281,28 @@ static int render_pass(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	// (--shade-triangles: a triangle hit recurses too)
 	p.shade_triangles = (opt->shade_triangles && p.n_tris > 0) ? 1 : 0;
 	p.tri_mats = r->d_blob + r->off_tri_mats;
-	if(!p.monte_carlo || (p.n_spheres == 0 && !p.shade_triangles) || p.num_path_traces == 0) p.max_depth = 1;
-	if(p.shade_triangles)
-	{ // only the lane-per-pixel kernel shades triangles (include/skr.h skr_options.shade_triangles)
+	p.legacy_reflect = (opt->legacy_reflect && p.n_spheres > 0) ? 1 : 0; // (only a sphere hit has the terms of raytrace.h:45-103)
+	if(p.legacy_reflect && p.shade_triangles)
+	{
+		skr_set_error("--legacy-reflect and --shade-triangles are separate modes of the lane-per-pixel kernel: choose one");
+		return SKR_ERR_UNSUPPORTED;
+	}
+	if(!p.legacy_reflect && (!p.monte_carlo || (p.n_spheres == 0 && !p.shade_triangles) || p.num_path_traces == 0)) p.max_depth = 1;
+	if(p.shade_triangles || p.legacy_reflect)
+	{ // only the lane-per-pixel kernel has these modes (include/skr.h skr_options.shade_triangles, .legacy_reflect)
 		p.sw.pipeline = SKR_PIPE_MEGA;
 		p.sw.kernel_v1 = 1;
 		if(p.max_depth > 6)
 		{
-			skr_set_error("--shade-triangles renders --depth <= 6 (asked for %d)", p.max_depth);
+			skr_set_error("%s renders --depth <= 6 (asked for %d)", p.shade_triangles ? "--shade-triangles" : "--legacy-reflect", p.max_depth);
 			return SKR_ERR_UNSUPPORTED;
 		}
 	}
 	if(p.max_depth > 1)
 	{ // tree node ids are 32-bit RNG counter words: need N^(depth-1) < 2^32
 		double nodes = 1;
-		for(int k = 1; k < p.max_depth && nodes < 4294967296.0; k++) nodes = nodes * (double) p.num_path_traces + 1;
+		const double arity = (double) (p.monte_carlo ? p.num_path_traces : 0) + (p.legacy_reflect ? 2.0 * p.n_lights : 0.0); // children per node
+		for(int k = 1; k < p.max_depth && nodes < 4294967296.0; k++) nodes = nodes * arity + 1;
 		if(nodes >= 4294967296.0)
 		{
 			skr_set_error("gillum %d at depth %d needs more than 2^32 tree nodes per sample", p.num_path_traces, p.max_depth);

@@ -5,7 +5,7 @@
 // messages and the exit-status-0 convention follow the reference.  New,
 // non-colliding flags: --seed u64 (counter-RNG key; the reference seeds rand()
 // with time(0)), --device i, --quiet (no per-line scene echo), --gpus N, --strict-scn,
-// --shade-triangles, --progressive K [--progressive-every M], --format ppm|png|pfm.
+// --shade-triangles, --legacy-reflect, --progressive K [--progressive-every M], --format ppm|png|pfm.
 // The frame itself is rendered by libskr on the GPU; there is no CPU path here.
 #include <cstdio>
 #include <cstdlib>
@@ -120,6 +120,7 @@ int main(int argc, char *argv[])
 		if(!strcmp(argv[i], "--quiet")) quiet = true;
 		if(!strcmp(argv[i], "--strict-scn")) strict_scn = true;
 		if(!strcmp(argv[i], "--shade-triangles")) option.shade_triangles = 1; // new: triangles as surfaces (include/skr.h skr_options)
+		if(!strcmp(argv[i], "--legacy-reflect")) option.legacy_reflect = 1;   // new: the reflection / refraction code behind raytrace.h:44's early return
 		if(!strcmp(argv[i], "--progressive") && has_next) option.progressive_passes = atoi(argv[i + 1]) > 1 ? atoi(argv[i + 1]) : 1; // new: mean of K frames, seeds seed..seed+K-1
 		if(!strcmp(argv[i], "--progressive-every") && has_next) progressive_every = (uint32_t) (atoi(argv[i + 1]) > 0 ? atoi(argv[i + 1]) : 0);
 		if(!strcmp(argv[i], "--format") && has_next) format = argv[i + 1];

@@ -192,11 +192,104 @@ SKR_DEV f3 shade_surfaces(const SceneView &sv, const RenderParams &p, f3 o, f3 d
 	}
 }
 
+// ---- --legacy-reflect (the rules: include/skr.h skr_options.legacy_reflect) ----
+// The code behind the early return of raytrace.h:44: Fresnel term, one refraction and one reflection ray per light from the hit
+// point itself, each shade(depth - 1), added to the direct term.  Unreachable at HEAD.  Out of line on purpose: three call
+// sites per level.
+
+// blinn_phong.h:156-184 (its unqualified sqrt is ::sqrt(double); powf(x, 2.0f) == x * x; utils.h:132-146 clamp)
+SKR_DEV float legacy_fresnel(f3 dir, f3 N, float mat_ior)
+{
+	float cos_internal = dot3(dir, N);
+	cos_internal = cos_internal < -1.0f ? -1.0f : (cos_internal > 1.0f ? 1.0f : cos_internal);
+	float et = 1.0f, ior = mat_ior;
+	if(cos_internal > 0)
+	{
+		const float t = et;
+		et = ior;
+		ior = t;
+	}
+	const float sint = (float) ((double) sk_divf(et, ior) * sqrt((double) max0(1.0f - cos_internal * cos_internal)));
+	if(sint >= 1.0f) return 1.0f;
+	const float cos_theta = (float) sqrt((double) max0(1 - sint * sint));
+	cos_internal = __builtin_fabsf(cos_internal);
+	const float Rs = sk_divf((ior * cos_internal) - (et * cos_theta), (ior * cos_internal) + (et * cos_theta));
+	const float Rp = sk_divf((et * cos_internal) - (ior * cos_theta), (ior * cos_internal) + (et * cos_theta));
+	return sk_divf(Rs * Rs + Rp * Rp, 2.0f);
+}
+
+template <int LEVELS>
+static __device__ __attribute__((noinline)) f3 shade_legacy(const SceneView &sv, const RenderParams &p, f3 o, f3 d, uint32_t node, uint32_t pixel, uint32_t aa, Counters &cn)
+{
+	if constexpr(LEVELS <= 0) return mk3(0, 0, 0);
+	else
+	{
+		cn.rays++;
+		const RayConst r = make_ray(o, d);
+		float tmin;
+		const int sph = closest_sphere(sv, r, tmin);
+		if(sv.nt > 0 && any_triangle_closer(sv, r, tmin)) return mk3(0, 0, 0);
+		if(sph < 0) return p.background;
+		cn.hits++;
+		const f3 P = o + d * tmin;
+		const f3 N = normalize3(P - ld3(sv.geom[sph]));
+		f3 direct = direct_light(sv, p, sph, P, N, cn);
+		const uint32_t A = (uint32_t) p.num_path_traces + 2u * (uint32_t) sv.nl; // children per node: the --gillum rays, then two per light
+		{ // raytrace.h:45-103
+			const float4 ks4 = sv.ks[sph];
+			const f3 ks = ld3(ks4);
+			const float mat_ior = ks4.w;
+			const float fr = legacy_fresnel(d, N, mat_ior);
+			f3 refraction_colour = mk3(0, 0, 0), reflection_colour = mk3(0, 0, 0);
+			if(ks.x != 0.0f || ks.y != 0.0f || ks.z != 0.0f)
+			{ // (depth > 0 holds here)
+				const uint32_t base = node * A + (uint32_t) p.num_path_traces + 1u;
+				for(int i = 0; i < sv.nl; i++)
+				{
+					const f3 L = light_term(sv, i, P).L; // glm::normalize(position - P) / normalize(direction)
+					if(fr < 1)
+					{ // blinn_phong.h:143-153
+						const float dn = dot3(d, N);
+						const float k = 1.0f - (mat_ior * mat_ior) * (1.0f - dn * dn);
+						const f3 rd = (k < 0.0f) ? mk3(0, 0, 0) : (d * mat_ior - N * (mat_ior * dn + sk_sqrtf(k)));
+						refraction_colour = shade_legacy<LEVELS - 1>(sv, p, P, rd, base + 2u * (uint32_t) i, pixel, aa, cn) * fr; // (=, not +=)
+					}
+					const f3 md = normalize3(L - N * (2.0f * dot3(L, N))); // blinn_phong.h:137-140: the LIGHT direction mirrored
+					const f3 c = shade_legacy<LEVELS - 1>(sv, p, P, md, base + 2u * (uint32_t) i + 1u, pixel, aa, cn);
+					reflection_colour = reflection_colour + (ks * (1 - fr)) * c;
+				}
+			}
+			direct = (direct + refraction_colour) + reflection_colour; // :102
+		}
+		if(!p.monte_carlo) return direct;
+
+		f3 total = mk3(0, 0, 0);
+		if constexpr(LEVELS > 1)
+		{
+			f3 nt, nb;
+			tangent_basis(N, nt, nb);
+			const float pdf = (float) (1 / 3.14159265358979323846);
+			const f3 co = add_scalar(P, 0.00001f);
+			uint32_t rnd[4];
+			for(int i = 0; i < p.num_path_traces; i++)
+			{
+				if((i & 1) == 0) philox4x32_10(pixel, aa, node, (uint32_t) i >> 1, p.seed_lo, p.seed_hi, rnd);
+				const float r1 = u31_to_unit(rnd[2 * (i & 1)]), r2 = u31_to_unit(rnd[2 * (i & 1) + 1]);
+				const f3 w = gi_direction(r1, r2, N, nt, nb);
+				const f3 child = shade_legacy<LEVELS - 1>(sv, p, co, w, node * A + (uint32_t) i + 1u, pixel, aa, cn);
+				total = total + (child * r1) / pdf;
+			}
+		}
+		total = total / (float) p.num_path_traces;
+		return (direct / (float) 3.14159265358979323846 + total * 2.0f) * ld3(sv.kd[sph]);
+	}
+}
+
 } // namespace
 
 // One workgroup = 4 waves = a 16x16 pixel tile; each wave owns an 8x8 sub-tile.
 // Dynamic LDS: scene SoA | 16 rows x 48 bytes of packed RGB for the tile.
-template <int DEPTH, bool SURFACES>
+template <int DEPTH, int MODE> // MODE 0: HEAD; 1: --shade-triangles; 2: --legacy-reflect
 __global__ __launch_bounds__(256) void skr_render_kernel(const RenderParams p)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -243,7 +336,8 @@ __global__ __launch_bounds__(256) void skr_render_kernel(const RenderParams p)
 				const float u = ((2 * (((float) x + r) * p.inv_width) - 1) * p.angle) * p.aspect;
 				const float v = (1 - 2 * (((float) (int) y + r) * p.inv_height)) * p.angle;
 				const f3 dir = (p.cam_dir + p.cam_right * u) + p.cam_up * v;
-				if constexpr(SURFACES) px = px + shade_surfaces<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, (uint32_t) s, -1, cn);
+				if constexpr(MODE == 1) px = px + shade_surfaces<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, (uint32_t) s, -1, cn);
+				else if constexpr(MODE == 2) px = px + shade_legacy<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, (uint32_t) s, cn);
 				else px = px + shade<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, (uint32_t) s, cn);
 			}
 			px = px / (float) ns2;
@@ -253,7 +347,8 @@ __global__ __launch_bounds__(256) void skr_render_kernel(const RenderParams p)
 			const float u = (float) (((2 * (((double) x + 0.5) * (double) p.inv_width) - 1) * (double) p.angle) * (double) p.aspect);
 			const float v = (float) ((1 - 2 * (((double) (int) y + 0.5) * (double) p.inv_height)) * (double) p.angle);
 			const f3 dir = (p.cam_dir + p.cam_right * u) + p.cam_up * v;
-			if constexpr(SURFACES) px = shade_surfaces<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, 0u, -1, cn);
+			if constexpr(MODE == 1) px = shade_surfaces<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, 0u, -1, cn);
+			else if constexpr(MODE == 2) px = shade_legacy<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, 0u, cn);
 			else px = shade<DEPTH>(sv, p, p.cam_pos, dir, 0u, pixel, 0u, cn);
 		}
 		if(p.rgbf)
@@ -348,8 +443,9 @@ size_t skr_render_lds_bytes(const RenderParams &p)
 template <int D>
 static hipError_t launch_depth(const RenderParams &p, dim3 grid, size_t lds, hipStream_t stream)
 {
-	if(p.shade_triangles) hipLaunchKernelGGL((skr_render_kernel<D, true>), grid, dim3(256), lds, stream, p);
-	else hipLaunchKernelGGL((skr_render_kernel<D, false>), grid, dim3(256), lds, stream, p);
+	if(p.legacy_reflect) hipLaunchKernelGGL((skr_render_kernel<D, 2>), grid, dim3(256), lds, stream, p);
+	else if(p.shade_triangles) hipLaunchKernelGGL((skr_render_kernel<D, 1>), grid, dim3(256), lds, stream, p);
+	else hipLaunchKernelGGL((skr_render_kernel<D, 0>), grid, dim3(256), lds, stream, p);
 	return hipGetLastError();
 }
 
@@ -380,7 +476,7 @@ hipError_t skr_launch_render(const RenderParams &p, hipStream_t stream, const ch
 	}
 	const dim3 grid((p.width + 15) / 16, (p.out_rows + 15) / 16);
 	const size_t lds = skr_render_lds_bytes(p);
-	*variant = p.shade_triangles ? "lane_per_pixel_surfaces_v1s" : "lane_per_pixel_dfs_v1f";
+	*variant = p.legacy_reflect ? "lane_per_pixel_legacy_v1r" : p.shade_triangles ? "lane_per_pixel_surfaces_v1s" : "lane_per_pixel_dfs_v1f";
 	if(hook && hook->start) (void) hipEventRecord(hook->start, stream);
 	hipError_t e = hipErrorInvalidValue;
 	switch(p.max_depth)

@@ -90,6 +90,7 @@ struct RenderParams {
 	uint32_t trace_chunks_max; // (host) bound on the trace kernel's 64-pair chunks: sizes rc_cap
 	// --shade-triangles (lane-per-pixel kernel only): triangles are surfaces, not black holes
 	int32_t shade_triangles;
+	int32_t legacy_reflect;   // --legacy-reflect (lane-per-pixel kernel only): raytrace.h:45-103 runs; sph_ks[i].w = the sphere's index of refraction
 	const float4 *tri_mats;   // 3 float4 per triangle, in tris[] order: [La*ka, power] [kd] [ks] (the rows sph_amb / sph_kd / sph_ks hold for a sphere)
 };
 

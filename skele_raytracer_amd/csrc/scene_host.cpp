@@ -45,6 +45,7 @@ int read_floats(const char *p, float *dst, int n)
 struct Material { // material.h:9-17
 	float ambient[3] = {0, 0, 0}, diffuse[3] = {0, 0, 0}, specular[3] = {0, 0, 0};
 	float power = 1.0f;
+	float ior = 1.0f; // (only the dead code of raytrace.h:45-103 reads it: --legacy-reflect)
 };
 
 } // namespace
@@ -62,7 +63,7 @@ void skr_scene::finalize()
 		sph_geom[i] = {s[0], s[1], s[2], s[3] * s[3]};
 		sph_amb[i] = {info.ambient[0] * s[4], info.ambient[1] * s[5], info.ambient[2] * s[6], s[13]};
 		sph_kd[i] = {s[7], s[8], s[9], 0.0f};
-		sph_ks[i] = {s[10], s[11], s[12], 0.0f};
+		sph_ks[i] = {s[10], s[11], s[12], (size_t) i < raw_sphere_ior.size() ? raw_sphere_ior[i] : 1.0f};
 	}
 	// point lights first, then (--strict-scn) the directional ones: the order blinn_phong.h:50-85 / :95-131 adds them in
 	const int nd = (int) (raw_directional_lights.size() / 6);
@@ -514,6 +515,7 @@ int skr_parse_scn(const std::string &path, bool echo, bool strict, skr_scene &sc
 			const float rec[14] = {v[0], v[1], v[2], v[3], mat.ambient[0], mat.ambient[1], mat.ambient[2],
 								   mat.diffuse[0], mat.diffuse[1], mat.diffuse[2], mat.specular[0], mat.specular[1], mat.specular[2], mat.power};
 			sc.raw_spheres.insert(sc.raw_spheres.end(), rec, rec + 14);
+			sc.raw_sphere_ior.push_back(mat.ior);
 			info.n_spheres++;
 		}
 		else if(cmd == "vertex")
@@ -586,7 +588,8 @@ int skr_parse_scn(const std::string &path, bool echo, bool strict, skr_scene &sc
 			memcpy(mat.ambient, v, 12);
 			memcpy(mat.diffuse, v + 3, 12);
 			memcpy(mat.specular, v + 6, 12);
-			mat.power = v[9]; // transmissive colour and ior feed only dead code (raytrace.h:45-103)
+			mat.power = v[9]; // the transmissive colour feeds only dead code (raytrace.h:45-103)
+			mat.ior = v[13];  // so does this one: kept for --legacy-reflect
 		}
 		else if(cmd == "directional_light")
 		{
@@ -711,6 +714,18 @@ int skr_scene_set_triangle_materials(skr_scene *scene, const float *materials)
 	return SKR_OK;
 }
 
+int skr_scene_set_sphere_ior(skr_scene *scene, const float *ior)
+{
+	if(!scene || (scene->info.n_spheres && !ior))
+	{
+		skr_set_error("skr_scene_set_sphere_ior: bad argument");
+		return SKR_ERR_ARG;
+	}
+	scene->raw_sphere_ior.assign(ior, ior + scene->info.n_spheres);
+	for(int i = 0; i < scene->info.n_spheres; i++) scene->sph_ks[i].w = ior[i];
+	return SKR_OK;
+}
+
 void skr_scene_destroy(skr_scene *scene) { delete scene; }
 
 int skr_scene_get_info(const skr_scene *scene, skr_scene_info *info)
@@ -763,6 +778,7 @@ void skr_options_default(skr_options *opt)
 	opt->seed = 1;
 	opt->shade_triangles = 0;
 	opt->progressive_passes = 1;
+	opt->legacy_reflect = 0;
 }
 
 uint64_t skr_radiance_ray_count(const skr_options *opt)

@@ -19,6 +19,7 @@ struct skr_f4 {
 struct skr_scene {
 	// raw values as parsed (skr_scene_get_arrays, loader parity tests)
 	std::vector<float> raw_spheres;      // [n][14] centre radius ambient diffuse specular power
+	std::vector<float> raw_sphere_ior;   // [n] index of refraction (material.h:16); shorter than n = 1.0.  Read by --legacy-reflect only
 	std::vector<float> raw_triangles;    // [n][9]  v0 v1 v2
 	std::vector<float> raw_triangle_materials; // [n][10] ambient diffuse specular power: the material in force on each `triangle` line
 	                                     //         (read by --shade-triangles only; shorter than n = the default material, material.h:9-17)
@@ -31,7 +32,7 @@ struct skr_scene {
 	std::vector<skr_f4> sph_geom; // centre.xyz, radius*radius (utils.h:118 forms r*r per test; same product)
 	std::vector<skr_f4> sph_amb;  // ambient_light.colour * material.ambient (blinn_phong.h:15), .w = phong power
 	std::vector<skr_f4> sph_kd;   // material.diffuse
-	std::vector<skr_f4> sph_ks;   // material.specular
+	std::vector<skr_f4> sph_ks;   // material.specular, .w = index of refraction
 	std::vector<skr_f4> lights;   // [2*i] position (.w = 0) or, behind the point lights, direction (.w = 1: --strict-scn), [2*i+1] colour
 	std::vector<skr_f4> tris;     // [3*i] v0, [3*i+1] v1-v0, [3*i+2] v2-v0 (utils.h:183-184 subtractions); [3*i+1].w = the triangle's index in the file (int bits)
 	std::vector<skr_f4> tri_mats; // [3*i] La*ka, power  [3*i+1] kd  [3*i+2] ks of the triangle stored at tris[3*i] (--shade-triangles)

@@ -99,6 +99,25 @@ def main():
         dst = os.path.join(GOLD, "scene_dump_%s.txt.gz" % scn[:-4])
         gz_write(d, dst)
         manifest["scene_dumps"][scn] = {"file": os.path.basename(dst), "sha256_uncompressed": sha(d)}
+    # one of the reference's README pictures (a PNG screenshot, made when raytrace.h:45-103 still ran), box-filtered 4x: the visual
+    # check of --legacy-reflect (tests/test_legacy_reflect.py).  Data only; PIL decodes the PNG.
+    try:
+        import io
+        import numpy as np
+        from PIL import Image
+        src = os.path.join(REF, "renders", "shadows", "sample_pngs", "bp_jsample5_parallel_shadows.png")
+        im = np.asarray(Image.open(src).convert("RGB"))
+        h4, w4 = im.shape[0] // 4 * 4, im.shape[1] // 4 * 4
+        small = im[:h4, :w4].reshape(h4 // 4, 4, w4 // 4, 4, 3).astype(np.float32).mean(axis=(1, 3)).round().astype(np.uint8)
+        buf = io.BytesIO()
+        np.save(buf, small)
+        with open(os.path.join(GOLD, "readme_bp_jsample5_parallel_shadows_quarter.npy.gz"), "wb") as f:
+            f.write(gzip.compress(buf.getvalue(), 9, mtime=0))
+        manifest["reference_fixture"]["readme_bp_jsample5_parallel_shadows_quarter.npy.gz"] = {
+            "source": "renders/shadows/sample_pngs/bp_jsample5_parallel_shadows.png", "sha256_source": sha(src),
+            "meaning": "README picture (1919x1003 screenshot of the 1920x1080 window), mean of 4x4 pixel blocks, uint8 [250, 479, 3]"}
+    except ImportError:
+        print("PIL not importable: README picture fixture left as it is")
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("wrote", GOLD)
