@@ -102,8 +102,26 @@ SKR_DEV bool classify_child(const SceneView &sv, f3 co, f3 d, float two_a, float
 // =====================================================================================================================
 // trace: one lane per sibling pair of a node
 // =====================================================================================================================
+#ifndef SKR_TRACE_LOOP
+#define SKR_TRACE_LOOP 1 // A/B builds: 0 = one block of 256 pairs per workgroup, the grid sized for the worst case
+#endif
+#if SKR_TRACE_LOOP
+#define SKR_TRACE_STRIDE gridDim.x
+#else
+#define SKR_TRACE_STRIDE 0x40000000u
+#undef SKR_TRACE_GRID_MAX
+#define SKR_TRACE_GRID_MAX 0x7fffffffu
+#endif
+#ifndef SKR_TRACE_WAVES
+#define SKR_TRACE_WAVES 0 // waves per SIMD the trace kernel is held to (0: whatever its registers allow) — A/B builds
+#endif
+#if SKR_TRACE_WAVES
+#define SKR_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(SKR_TRACE_WAVES, SKR_TRACE_WAVES)))
+#else
+#define SKR_TRACE_ATTR
+#endif
 template <bool TRIS>
-__global__ __launch_bounds__(256) void skr_trace_kernel(const RenderParams p)
+__global__ __launch_bounds__(256) SKR_TRACE_ATTR void skr_trace_kernel(const RenderParams p)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
@@ -115,7 +133,7 @@ __global__ __launch_bounds__(256) void skr_trace_kernel(const RenderParams p)
 	Counters cn{0, 0, 0};
 	// (the grid is sized for the worst case — every ray of the level above a hit — and capped: a workgroup takes every
 	// gridDim.x-th block of 256 pairs, so a launch far below the worst case does not pay for its empty workgroups)
-	for(uint32_t blk = blockIdx.x; (uint64_t) blk * 256u < n_pairs; blk += gridDim.x)
+	for(uint32_t blk = blockIdx.x; (uint64_t) blk * 256u < n_pairs; blk += SKR_TRACE_STRIDE)
 	{
 	const uint32_t chunk = blk * 4u + (uint32_t) (tid >> 6);
 	const uint64_t tp = (uint64_t) chunk * 64u + (uint32_t) lane;
