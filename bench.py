@@ -279,10 +279,11 @@ def main():
         scene_bytes = info.n_spheres * 64 + info.n_point_lights * 32 + info.n_triangles * 48
         alg_bytes = W * H * 3 + scene_bytes
         achieved_gbs = alg_bytes / (ms_per_step * 1e-3) / 1e9
-        # the node pipeline's own records (one band = the frame): 48 B per level-0 node written and read three times, 32 B per level-1 record
-        # written and read, 4 B per child index word written and read, 12 B per record result written and read
+        # the node pipeline's own tables (one band = the frame): a level-0 node is a 32-byte geometry row (read by the trace kernel and, gathered,
+        # by the leaf kernel) and a 32-byte shading row (read by finalize); a level-1 record is 16 bytes written and read, its result 12 bytes
+        # written and read; every trace wave (64 sibling pairs) leaves a 48-byte header that finalize reads
         N = KW["gillum"]
-        pipeline_bytes = (queued * (48 * 4 + 2 * 4 * N) + level1 * (2 * 32 + 3 * 12)) if variant == "node_levels_v5" else None
+        pipeline_bytes = (queued * (64 + 3 * 32) + level1 * (2 * 16 + 2 * 12) + (queued * ((N + 1) // 2) + 63) // 64 * 48 * 2) if variant == "node_levels_v5" else None
         tj, why = measured_traffic(variant) if world == 1 else (None, "measured at N = 1 only")
         traffic = tj["traffic_bytes_per_frame"] if tj else None
         # ---- FP32-VALU roofline: the flops the reference's algorithm needs for this frame — every ray-sphere test it would run (early-outs of the

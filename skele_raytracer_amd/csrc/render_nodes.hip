@@ -33,9 +33,12 @@
 
 namespace {
 
-// One 16-bit code per sibling pair tells finalize what became of its two children; their record indices follow from the trace
-// wave's base (one 8-byte header per 64 pairs) and the ranks in the code, their r1 from the same Philox call the trace made.
-constexpr uint32_t PC_HIT0 = 1u, PC_HIT1 = 2u, PC_BLACK0 = 4u, PC_BLACK1 = 8u; // | rank of child 2j among the wave's even hits << 4 | rank of child 2j+1 among its odd hits << 10
+// One header per trace wave (64 sibling pairs) tells finalize what became of their children: [0] = {first record of the wave's
+// hits, -, -, -}, [1] = the ballots of the even and the odd children that hit a sphere (2 x 64 bits: a child's record is the
+// base + the number of set bits below its pair, the odd children's records behind the even ones'), [2] (triangle scenes only) =
+// the ballots of the children a triangle took.  r1 of a miss comes from the same Philox call the trace made.
+constexpr uint32_t PC_HIT0 = 1u, PC_HIT1 = 2u, PC_BLACK0 = 4u, PC_BLACK1 = 8u; // (finalize's per-pair flags, formed from the ballots)
+constexpr int IXH_ROWS = 3; // uint4 per header
 constexpr int NQ_CAP = 176;                 // leaf-hit ring: <= NQ_PRE left over when a round starts + the 128 hits it can add
 constexpr int NQ_PRE = NQ_CAP - 128;        // more than that waiting at the start of a round: one (>= 3/4 full) batch is shaded first
 constexpr int NQ_F = 5;                     // dwords per entry: d.xyz, ids, r1 (b and D of utils.h:116-118 are formed again from d when the hit is shaded)
@@ -145,10 +148,10 @@ __global__ __launch_bounds__(256) SKR_TRACE_ATTR void skr_trace_kernel(const Ren
 	bool black0 = false, black1 = false;
 	if(valid)
 	{
-		const float4 *row = p.nd_src + (size_t) node * p.nd_src_stride;
-		const float4 a0 = row[0], a1 = row[1], a2 = row[2];
+		const float4 *row = p.nd_src + (size_t) node * 2;
+		const float4 a0 = row[0], a1 = row[1];
 		const f3 co = mk3(a0.x, a0.y, a0.z), Nn = mk3(a0.w, a1.x, a1.y);
-		const uint32_t pixel = __float_as_uint(a2.y), node_id = p.nd_src_level0 ? 0u : __float_as_uint(a2.z);
+		const uint32_t pixel = __float_as_uint(a1.z), node_id = __float_as_uint(a1.w);
 		f3 nt, nb;
 		tangent_basis(Nn, nt, nb);
 		uint32_t rnd[4];
@@ -181,8 +184,16 @@ __global__ __launch_bounds__(256) SKR_TRACE_ATTR void skr_trace_kernel(const Ren
 	const uint32_t rank0 = (uint32_t) lanes_below(m0), rank1 = (uint32_t) lanes_below(m1);
 	if(hit0) p.rc[rec_base + rank0] = rec0;
 	if(hit1) p.rc[rec_base + n0h + rank1] = rec1;
-	if(valid) p.ix16[tp] = (uint16_t) ((hit0 ? PC_HIT0 : 0u) | (hit1 ? PC_HIT1 : 0u) | (black0 ? PC_BLACK0 : 0u) | (black1 ? PC_BLACK1 : 0u) | (rank0 << 4) | (rank1 << 10));
-	if(lane == 0) p.ixh[chunk] = make_uint2(rec_base, n0h);
+	if(TRIS)
+	{
+		const unsigned long long k0 = __ballot(black0), k1 = __ballot(black1);
+		if(lane == 0) p.ixh[IXH_ROWS * (size_t) chunk + 2] = make_uint4((uint32_t) k0, (uint32_t) (k0 >> 32), (uint32_t) k1, (uint32_t) (k1 >> 32));
+	}
+	if(lane == 0)
+	{
+		p.ixh[IXH_ROWS * (size_t) chunk] = make_uint4(rec_base, n0h, 0u, 0u);
+		p.ixh[IXH_ROWS * (size_t) chunk + 1] = make_uint4((uint32_t) m0, (uint32_t) (m0 >> 32), (uint32_t) m1, (uint32_t) (m1 >> 32));
+	}
 	}
 	add_counters(p, cn, (uint32_t) blockIdx.x * 4u + (uint32_t) (tid >> 6), lane);
 }
@@ -240,11 +251,11 @@ SKR_DEV Activated activate_record(const SceneView &sv, const RenderParams &p, bo
 		a.r1 = n0.z;
 		a.sph = sc & 0xffffu;
 		a.child = sc >> 16;
-		const float4 *row = p.nd_src + (size_t) parent * p.nd_src_stride;
-		const float4 p0 = row[0], p1 = row[1], p2 = row[2];
+		const float4 *row = p.nd_src + (size_t) parent * 2; // (one aligned 32-byte sector per parent)
+		const float4 p0 = row[0], p1 = row[1];
 		const f3 co0 = mk3(p0.x, p0.y, p0.z), N0 = mk3(p0.w, p1.x, p1.y);
-		a.pixel = __float_as_uint(p2.y);
-		const uint32_t pnode = p.nd_src_level0 ? 0u : __float_as_uint(p2.z);
+		a.pixel = __float_as_uint(p1.z);
+		const uint32_t pnode = __float_as_uint(p1.w); // (0 at level 0)
 		a.node_id = pnode * (uint32_t) p.num_path_traces + a.child + 1u; // DESIGN.md "RNG": child c of node n
 		// The ray that found this hit, formed again from its two draws exactly as the trace kernel formed it (raytrace.h:119-125:
 		// same operations on the same values, so the same direction), and utils.h:115-118 for the sphere it hit: 16 bytes per
@@ -288,11 +299,12 @@ __global__ __launch_bounds__(256) void skr_activate_kernel(const RenderParams p)
 	const Activated a = activate_record(sv, p, act, rec, cn);
 	if(act)
 	{
-		float4 *row = p.nd_dst + (size_t) (s_pre[region] + pos) * 4;
-		row[0] = make_float4(a.co.x, a.co.y, a.co.z, a.N.x);
-		row[1] = make_float4(a.N.y, a.N.z, a.direct.x, a.direct.y);
-		row[2] = make_float4(a.direct.z, __uint_as_float(a.pixel), __uint_as_float(a.node_id), __uint_as_float(a.sph));
-		row[3] = make_float4(a.r1, __uint_as_float(rec), 0.0f, 0.0f);
+		const size_t n = (size_t) (s_pre[region] + pos);
+		float4 *grow = p.nd_dst + n * 2, *srow = p.ns_dst + n * 2;
+		grow[0] = make_float4(a.co.x, a.co.y, a.co.z, a.N.x);
+		grow[1] = make_float4(a.N.y, a.N.z, __uint_as_float(a.pixel), __uint_as_float(a.node_id));
+		srow[0] = make_float4(a.direct.x, a.direct.y, a.direct.z, __uint_as_float(a.sph));
+		srow[1] = make_float4(a.r1, __uint_as_float(rec), __uint_as_float(a.pixel), __uint_as_float(a.node_id));
 	}
 	add_counters(p, cn, blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63);
 }
@@ -528,13 +540,13 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 		{
 			if(act0)
 			{
-				const float4 *row = p.nd_src + (size_t) (first + (uint32_t) lane) * p.nd_src_stride;
-				const float4 a0 = row[0], a1 = row[1], a2 = row[2];
+				const size_t nn = (size_t) (first + (uint32_t) lane);
+				const float4 a0 = p.nd_src[nn * 2], a1 = p.nd_src[nn * 2 + 1], b0 = p.ns_src[nn * 2], b1 = p.ns_src[nn * 2 + 1];
 				co = mk3(a0.x, a0.y, a0.z);
 				Nn = mk3(a0.w, a1.x, a1.y);
-				direct1 = mk3(a1.z, a1.w, a2.x);
-				pixel = __float_as_uint(a2.y);
-				out_idx = __float_as_uint(a2.z);
+				direct1 = mk3(b0.x, b0.y, b0.z);
+				pixel = __float_as_uint(a1.z);
+				out_idx = __float_as_uint(b1.y);
 			}
 		}
 		else
@@ -582,8 +594,11 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 				q1a = u31_to_unit(rnd[0]);
 				q1b = u31_to_unit(rnd[2]);
 				const float q2a = u31_to_unit(rnd[1]), q2b = u31_to_unit(rnd[3]);
-				d0 = gi_direction(q1a, q2a, Nn, nt, nb);
-				d1 = gi_direction(q1b, q2b, Nn, nt, nb);
+				f3 nq = Nn;
+				asm volatile("" : "+v"(nq.x), "+v"(nq.y), "+v"(nq.z)); // (keeps the next line inside the loop)
+				const f3 nbr = cross3(nq, nt); // (utils.h:164, formed again per round: three registers less to carry)
+				d0 = gi_direction(q1a, q2a, Nn, nt, nbr);
+				d1 = gi_direction(q1b, q2b, Nn, nt, nbr);
 				cn.rays += second ? 2u : 1u;
 				const RayPair rp = make_pair(d0, d1);
 				BestState s0, s1;
@@ -652,10 +667,8 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 			float r1 = 0.0f;
 			if(FIRST)
 			{
-				const float4 *row = p.nd_src + (size_t) (first + (uint32_t) lane) * p.nd_src_stride;
-				const float4 a2 = row[2];
 				direct = direct1;
-				sph = __float_as_uint(a2.w);
+				sph = __float_as_uint(p.ns_src[(size_t) (first + (uint32_t) lane) * 2].w);
 			}
 			else
 			{
@@ -704,9 +717,9 @@ __global__ __launch_bounds__(256) void skr_finalize_kernel2(const RenderParams p
 	if(node >= n) return;
 	const int N = p.num_path_traces, PP = (N + 1) >> 1;
 	const float pdf = (float) (1 / 3.14159265358979323846);
-	const float4 *row = p.nd_src + (size_t) node * p.nd_src_stride;
-	const float4 a1 = row[1], a2 = row[2];
-	const uint32_t pixel = __float_as_uint(a2.y), node_id = p.nd_src_level0 ? 0u : __float_as_uint(a2.z);
+	const float4 *row = p.ns_src + (size_t) node * 2; // the shading row is all this kernel reads of a node
+	const float4 b0 = row[0], b1 = row[1];
+	const uint32_t pixel = __float_as_uint(b1.z), node_id = __float_as_uint(b1.w);
 	f3 total = mk3(0, 0, 0);
 	for(int j0 = 0; j0 < PP; j0 += 4)
 	{ // 4 sibling pairs (8 children) per trip: codes, headers and every gather issued before the first add
@@ -720,10 +733,20 @@ __global__ __launch_bounds__(256) void skr_finalize_kernel2(const RenderParams p
 			rec[2 * k] = rec[2 * k + 1] = 0;
 			if(j0 + k < PP)
 			{
-				code[k] = p.ix16[tp];
-				const uint2 h = p.ixh[tp >> 6];
-				rec[2 * k] = h.x + ((code[k] >> 4) & 63u);
-				rec[2 * k + 1] = h.x + h.y + ((code[k] >> 10) & 63u);
+				const uint4 *h = p.ixh + IXH_ROWS * (size_t) (tp >> 6);
+				const uint4 h0 = h[0], h1 = h[1];
+				const unsigned long long m0 = (unsigned long long) h1.y << 32 | h1.x, m1 = (unsigned long long) h1.w << 32 | h1.z;
+				const uint32_t bit = (uint32_t) tp & 63u;
+				const unsigned long long below = (1ull << bit) - 1ull;
+				code[k] = (uint32_t) ((m0 >> bit) & 1ull) * PC_HIT0 | (uint32_t) ((m1 >> bit) & 1ull) * PC_HIT1;
+				if(p.n_tris > 0)
+				{
+					const uint4 h2 = h[2];
+					const unsigned long long k0 = (unsigned long long) h2.y << 32 | h2.x, k1 = (unsigned long long) h2.w << 32 | h2.z;
+					code[k] |= (uint32_t) ((k0 >> bit) & 1ull) * PC_BLACK0 | (uint32_t) ((k1 >> bit) & 1ull) * PC_BLACK1;
+				}
+				rec[2 * k] = h0.x + (uint32_t) __popcll(m0 & below);
+				rec[2 * k + 1] = h0.x + h0.y + (uint32_t) __popcll(m1 & below);
 			}
 		}
 #pragma unroll
@@ -760,16 +783,12 @@ __global__ __launch_bounds__(256) void skr_finalize_kernel2(const RenderParams p
 			}
 		}
 	}
-	const f3 direct = mk3(a1.z, a1.w, a2.x);
-	const uint32_t sph = __float_as_uint(a2.w);
+	const f3 direct = mk3(b0.x, b0.y, b0.z);
+	const uint32_t sph = __float_as_uint(b0.w);
 	total = total / (float) N;
 	const f3 colour = (direct / (float) 3.14159265358979323846 + total * 2.0f) * ld3(p.sph_kd[sph]); // raytrace.h:213
-	if(p.nd_src_level0) emit_sample(p, __float_as_uint(a2.z), colour);
-	else
-	{
-		const float4 a3 = row[3];
-		store3(p.res_out + (size_t) __float_as_uint(a3.y) * 3, (colour * a3.x) / pdf);
-	}
+	if(p.nd_src_level0) emit_sample(p, __float_as_uint(b1.y), colour);
+	else store3(p.res_out + (size_t) __float_as_uint(b1.y) * 3, (colour * b1.x) / pdf);
 }
 
 // =====================================================================================================================
@@ -789,10 +808,9 @@ struct NodePlan {
 	bool flat = false;       // the flat schedule (below): the leaves' hits are a record level of their own
 	int levels = 0;          // node / record levels 0 .. max_depth - 2 (flat: .. max_depth - 1)
 	uint32_t band_nblk = 0;  // 16x16 pixel blocks per band
-	uint32_t stride0 = 3;    // float4 per level-0 node
 	uint64_t nodes_max[SKR_NODE_LEVELS_MAX] = {};
 	uint32_t cap[SKR_NODE_LEVELS_MAX] = {};
-	size_t off_nodes[SKR_NODE_LEVELS_MAX] = {}, off_recs[SKR_NODE_LEVELS_MAX] = {}, off_res[SKR_NODE_LEVELS_MAX] = {}, off_ix[SKR_NODE_LEVELS_MAX] = {}, off_ixh[SKR_NODE_LEVELS_MAX] = {};
+	size_t off_nodes[SKR_NODE_LEVELS_MAX] = {}, off_shade[SKR_NODE_LEVELS_MAX] = {}, off_recs[SKR_NODE_LEVELS_MAX] = {}, off_res[SKR_NODE_LEVELS_MAX] = {}, off_ixh[SKR_NODE_LEVELS_MAX] = {};
 	size_t off_ctr = 0, ctr_bytes = 0, off_stash = 0, total = 0, banded = 0;
 };
 static uint32_t *lc_prefix_host(uint32_t *ctr) { return ctr + SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS + 1u) + 64; } // the level's record count (skr_prefix_kernel)
@@ -819,7 +837,6 @@ static bool plan_for(const RenderParams &p, uint32_t nblk, bool flat, NodePlan &
 	pl.levels = p.max_depth - 1 + (flat ? 1 : 0);
 	if(pl.levels < 1 || pl.levels > SKR_NODE_LEVELS_MAX) return false;
 	pl.band_nblk = nblk;
-	pl.stride0 = pl.levels <= 2 ? 3u : 4u; // (64-byte rows where skr_activate_kernel gathers its parents from them)
 	pl.nodes_max[0] = (uint64_t) nblk * 256u;
 	pl.cap[0] = 0;
 	for(int L = 1; L < pl.levels; L++)
@@ -838,17 +855,19 @@ static bool plan_for(const RenderParams &p, uint32_t nblk, bool flat, NodePlan &
 	for(int L = 0; L < pl.levels; L++)
 	{
 		const size_t n = (size_t) pl.nodes_max[L];
-		if(L == 0) pl.off_nodes[L] = take(n * pl.stride0 * 16);
-		else
+		if(L > 0)
 		{
 			pl.off_recs[L] = take(n * 16);
 			pl.off_res[L] = take(n * 12 + 16);
-			if(L < pl.levels - 1) pl.off_nodes[L] = take(n * 64);
+		}
+		if(L < pl.levels - 1 || pl.levels == 1)
+		{ // levels whose nodes exist (the last record level is only shaded): geometry rows and shading rows, 32 bytes each per node
+			pl.off_nodes[L] = take(n * 32);
+			pl.off_shade[L] = take(n * 32);
 		}
 		if(L < pl.levels - 1)
-		{ // the children of level L: a 16-bit code per sibling pair, an 8-byte header per trace wave (64 pairs)
-			pl.off_ix[L] = take(n * PP * 2 + 64);
-			pl.off_ixh[L] = take((n * PP + 63) / 64 * 8 + 64);
+		{ // the children of level L: a 48-byte header per trace wave (64 sibling pairs)
+			pl.off_ixh[L] = take(((n * PP + 63) / 64 + 4) * IXH_ROWS * 16);
 		}
 	}
 	pl.total = off;
@@ -954,7 +973,8 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 	char *base = reinterpret_cast<char *>(p.node_scratch);
 	uint32_t *ctr0 = reinterpret_cast<uint32_t *>(base + pl.off_ctr);
 	auto lvl_ctr = [&](int L) { return ctr0 + SKR_PULL_STRIDE + LVL_CTR_WORDS * (size_t) L; };
-	auto nodes = [&](int L) { return reinterpret_cast<float4 *>(base + pl.off_nodes[L]); };
+	auto nodes = [&](int L) { return reinterpret_cast<float4 *>(base + pl.off_nodes[L]); };   // geometry rows
+	auto shade = [&](int L) { return reinterpret_cast<float4 *>(base + pl.off_shade[L]); };   // shading rows
 	const int nsamp = p.grid_size > 0 ? p.grid_size * p.grid_size : 1;
 	const size_t lds_scene = ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 32;
 	const size_t lds_leaf = skr_nodes_lds_bytes(p);
@@ -978,13 +998,13 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 			e = hipMemsetAsync(ctr0, 0, pl.ctr_bytes, stream);
 			if(e != hipSuccess) return e;
 			p.nd_dst = nodes(0);
-			p.nd_dst_stride = pl.stride0;
+			p.ns_dst = shade(0);
 			e = skr_launch_primary(p, dim3(p.band_nblk), lds_scene, stream);
 			if(e != hipSuccess) return e;
 			if(D == 2 && !flat)
 			{ // the level-0 nodes' children are the leaves
 				p.nd_src = nodes(0);
-				p.nd_src_stride = pl.stride0;
+				p.ns_src = shade(0);
 				p.nd_src_level0 = 1;
 				p.nd_count = ctr0;
 				p.rc_ctr = lvl_ctr(0);
@@ -997,14 +1017,13 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 			for(int L = 1; L <= last; L++)
 			{ // the children of level L - 1: hit records of level L, index words of level L - 1
 				p.nd_src = nodes(L - 1);
-				p.nd_src_stride = L == 1 ? pl.stride0 : 4u;
+				p.ns_src = shade(L - 1);
 				p.nd_src_level0 = L == 1;
 				p.nd_count = L == 1 ? ctr0 : lc_prefix_host(lvl_ctr(L - 1));
 				p.rc = reinterpret_cast<float4 *>(base + pl.off_recs[L]);
 				p.rc_cap = pl.cap[L];
 				p.rc_ctr = lvl_ctr(L);
-				p.ix16 = reinterpret_cast<uint16_t *>(base + pl.off_ix[L - 1]);
-				p.ixh = reinterpret_cast<uint2 *>(base + pl.off_ixh[L - 1]);
+				p.ixh = reinterpret_cast<uint4 *>(base + pl.off_ixh[L - 1]);
 				const uint64_t wg_t = (pl.nodes_max[L - 1] * (uint64_t) ((p.num_path_traces + 1) >> 1) + 255) / 256;
 				const unsigned grid_t = (unsigned) (wg_t < SKR_TRACE_GRID_MAX ? wg_t : SKR_TRACE_GRID_MAX);
 				if(flat && L == last && timed && hook->start) (void) hipEventRecord(hook->start, stream); // (flat: the last level's trace + shading are the dominant pair)
@@ -1013,7 +1032,7 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 				if(L < last)
 				{ // its records become the nodes of level L
 					p.nd_dst = nodes(L);
-					p.nd_dst_stride = 4;
+					p.ns_dst = shade(L);
 					const unsigned grid_a = SKR_P1_REGIONS * ((pl.cap[L] + 255u) / 256u);
 					if(tris) hipLaunchKernelGGL(skr_activate_kernel<true>, dim3(grid_a), dim3(256), lds_scene, stream, p);
 					else hipLaunchKernelGGL(skr_activate_kernel<false>, dim3(grid_a), dim3(256), lds_scene, stream, p);
@@ -1038,11 +1057,10 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 			for(int L = last - 1; L >= 0; L--)
 			{ // sums, deepest level first
 				p.nd_src = nodes(L);
-				p.nd_src_stride = L == 0 ? pl.stride0 : 4u;
+				p.ns_src = shade(L);
 				p.nd_src_level0 = L == 0;
 				p.nd_count = L == 0 ? ctr0 : lc_prefix_host(lvl_ctr(L));
-				p.ix16 = reinterpret_cast<uint16_t *>(base + pl.off_ix[L]);
-				p.ixh = reinterpret_cast<uint2 *>(base + pl.off_ixh[L]);
+				p.ixh = reinterpret_cast<uint4 *>(base + pl.off_ixh[L]);
 				p.res_in = reinterpret_cast<const float *>(base + pl.off_res[L + 1]);
 				p.res_out = L == 0 ? nullptr : reinterpret_cast<float *>(base + pl.off_res[L]);
 				hipLaunchKernelGGL(skr_finalize_kernel2, dim3((unsigned) ((pl.nodes_max[L] + 255) / 256)), dim3(256), 0, stream, p);

@@ -69,19 +69,19 @@ struct RenderParams {
 	float *acc;         // float3 per output pixel: the running `image[y][x] += shade(...)` of main.cpp:162 (AA only)
 	uint32_t aa_index;  // which AA sample this launch traces
 	// node pipeline (render_nodes.hip): the --gillum tree cut at every level.  A node is a shaded sphere hit; level 0 = the
-	// primary hits.  Node row layout (float4): [co.xyz N.x] [N.yz direct.xy] [direct.z pixel (out_pix | node id) sphere]
-	// [r1 record -- --] (the fourth row only at nd_stride 4: levels >= 1).
-	uint32_t node_layout;     // skr_primary_kernel writes its hits as level-0 nodes (nd_dst, nd_dst_stride) instead of 64-byte parent records
-	const float4 *nd_src;     // nodes whose children are traced / summed
-	float4 *nd_dst;           // nodes being written (primary hits; activated records)
-	uint32_t nd_src_stride, nd_dst_stride; // float4 per node: 3 or 4
-	uint32_t nd_src_level0;   // nd_src holds the primary hits: node id 0, row 2.z = output pixel index
+	// primary hits.  A node is two rows of two float4 in two arrays, so that every kernel reads only the half it needs:
+	//   geometry (tracing its children): [co.xyz N.x] [N.yz pixel node-id]                       (node id 0 at level 0)
+	//   shading  (summing them):         [direct.xyz sphere] [r1 record|output-pixel pixel node-id]   (level 0: output pixel; deeper: its own record)
+	uint32_t node_layout;     // skr_primary_kernel writes its hits as level-0 nodes (nd_dst, ns_dst) instead of 64-byte parent records
+	const float4 *nd_src;     // geometry rows of the nodes whose children are traced (trace, activate, leaf)
+	const float4 *ns_src;     // shading rows of the nodes whose children are summed (finalize, the depth-2 leaf kernel)
+	float4 *nd_dst, *ns_dst;  // nodes being written (primary hits; activated records)
+	uint32_t nd_src_level0;   // nd_src / ns_src hold the primary hits
 	const uint32_t *nd_count; // number of nodes in nd_src
 	float4 *rc;               // hit records of the level being produced (trace) or consumed (activate, leaf): [parent, sphere | child << 16, r1, r2]
 	uint32_t rc_cap;          // records per region (SKR_P1_REGIONS regions)
 	uint32_t *rc_ctr;         // that level's counters: [STRIDE r] records in region r, [STRIDE (64 + r)] units handed out, [STRIDE 128] exhausted mask, [STRIDE 129 ..] prefix sums
-	uint16_t *ix16;           // one code per sibling pair of the nd_src nodes, [node * PP + j]: hit / triangle flags of children 2j, 2j+1 and their ranks among the trace wave's hits
-	uint2 *ixh;               // per trace wave (64 pairs): {first record of its even children's hits, how many of those}; its odd children's hits follow
+	uint4 *ixh;               // per trace wave (64 sibling pairs of the nd_src nodes, pair = node * PP + j) three uint4: {first record of its hits, how many of them are even children's, -, -}, the ballots of the even / odd children that hit (64 bits each), the ballots of the children a triangle took (triangle scenes)
 	uint32_t band_blk0, band_nblk, blocks_x; // node_layout: skr_primary_kernel covers the 16x16 pixel blocks [band_blk0, band_blk0 + band_nblk) of the launch (row-major, blocks_x per row)
 	void *node_scratch;       // (host) the pipeline's one allocation
 	const float *res_in;      // (colour r1)/pdf of every child record (finalize)

@@ -881,10 +881,12 @@ __global__ __launch_bounds__(256) void skr_primary_kernel(const RenderParams p)
 		for(int wv = 0; wv < wave; wv++) idx += s_cnt[wv];
 		if(p.node_layout)
 		{ // a level-0 node of the node pipeline (render_params.h)
-			float4 *row = p.nd_dst + (size_t) idx * p.nd_dst_stride;
-			row[0] = make_float4(co.x, co.y, co.z, N.x);
-			row[1] = make_float4(N.y, N.z, colour.x, colour.y);
-			row[2] = make_float4(colour.z, __uint_as_float(pixel), __uint_as_float(out_pix), __uint_as_float((uint32_t) sph_hit));
+			// (render_params.h: a node is a 32-byte geometry row — what tracing its children needs — and a 32-byte shading row — what summing them needs)
+			float4 *grow = p.nd_dst + (size_t) idx * 2, *srow = p.ns_dst + (size_t) idx * 2;
+			grow[0] = make_float4(co.x, co.y, co.z, N.x);
+			grow[1] = make_float4(N.y, N.z, __uint_as_float(pixel), __uint_as_float(0u));
+			srow[0] = make_float4(colour.x, colour.y, colour.z, __uint_as_float((uint32_t) sph_hit));
+			srow[1] = make_float4(0.0f, __uint_as_float(out_pix), __uint_as_float(pixel), __uint_as_float(0u));
 		}
 		else
 		{
