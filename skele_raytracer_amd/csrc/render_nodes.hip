@@ -4,14 +4,16 @@
 // A *node* is a shaded sphere hit whose N children are to be traced; level 0 = the primary hits.  Rays of the last
 // level (their own children are shade(depth 0) == 0, raytrace.h:142-145) are leaves.  Kernels, in launch order:
 //
-//   skr_primary_kernel   (render_wave.hip) primary rays + direct light; every sphere hit becomes a level-0 node
+//   skr_primary_kernel   (render_wave.hip) primary rays + direct light; every sphere hit becomes a level-0 node (a 32-byte geometry
+//                        row for the kernels that trace its children, a 32-byte shading row for the one that sums them)
 //   skr_trace_kernel     one lane per sibling pair of a node: traces the two child rays (one Philox call, one (e, c)
-//                        per sphere for both); per pair one 16-bit code (hit / triangle flags and the ranks of its hits among
-//                        the wave's: finalize finds the records from them and the wave's 8-byte header, and draws r1 of
-//                        a miss again from the same Philox counter) and per sphere
-//                        hit a 16-byte record (parent, sphere, child, the two draws) appended to one of 64 regions (ballot ranks + one atomic per wave)
-//   skr_activate_kernel  (depth >= 4 only) one lane per record: shades the hit (:194-207) and writes it as a node of
-//                        the next level, which the trace kernel then expands
+//                        per sphere for both); per wave (64 pairs) one 48-byte header — the first record of its hits and the
+//                        ballots of the children that hit: finalize finds a child's record from the population count of the
+//                        ballot below its pair, and draws r1 of a miss again from the same Philox counter — and per sphere
+//                        hit a 16-byte record (parent, sphere, child, the two draws) appended to one of 64 regions (ballot
+//                        ranks + one atomic per wave).  The grid is capped; a workgroup strides over the blocks of 256 pairs.
+//   skr_activate_kernel  (depth >= 4, and the flat schedule) one lane per record: shades the hit (:194-207) and writes it as a
+//                        node of the next level, which the trace kernel then expands; forms the level's prefix sums itself
 //   skr_leaf_kernel2     persistent waves, one unit = 64 records of the last-but-one level, ONE LANE PER RECORD: the 64
 //                        hits are shaded full-width and stay in their lanes (origin, normal, basis, RNG key), then for
 //                        every sibling pair j the lanes trace children 2j, 2j+1 of their own node; leaf hits go through
@@ -19,7 +21,9 @@
 //                        windows (one round each) until they are added, strictly in child order (:130), to the
 //                        lane's running sum.  Depth 2: the units are the level-0 nodes themselves and the pixels are
 //                        written here.
-//   skr_finalize_kernel2 one lane per node, deepest level first: the N terms in child order from the pair codes,
+//   skr_shade_leaf_kernel (flat schedule: small launches, where the persistent kernel has one or two units per wave and a long
+//                        tail) the last level too is traced into records by skr_trace_kernel; this kernel shades them one per lane
+//   skr_finalize_kernel2 one lane per node, deepest level first: the N terms in child order from the wave headers,
 //                        (direct/pi + 2 indirect) * kd (:213), times r1/pdf into the parent's level — or the pixel
 //
 // Every float operation and every order of summation is the reference's (DESIGN.md "Arithmetic spec"); only the
@@ -813,7 +817,7 @@ struct NodePlan {
 	size_t off_nodes[SKR_NODE_LEVELS_MAX] = {}, off_shade[SKR_NODE_LEVELS_MAX] = {}, off_recs[SKR_NODE_LEVELS_MAX] = {}, off_res[SKR_NODE_LEVELS_MAX] = {}, off_ixh[SKR_NODE_LEVELS_MAX] = {};
 	size_t off_ctr = 0, ctr_bytes = 0, off_stash = 0, total = 0, banded = 0;
 };
-static uint32_t *lc_prefix_host(uint32_t *ctr) { return ctr + SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS + 1u) + 64; } // the level's record count (skr_prefix_kernel)
+static uint32_t *lc_prefix_host(uint32_t *ctr) { return ctr + SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS + 1u) + 64; } // the level's record count (region_prefix, published by skr_activate_kernel's first workgroup)
 static const uint32_t LEAF2_GRID = 256u * SKR_LEAF2_OCC;                   // every workgroup resident: 256 CUs x 4 workgroups of 4 waves
 static const size_t LVL_CTR_WORDS = (size_t) SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS + 2u); // counts, taken, mask, prefix
 
@@ -1015,7 +1019,7 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 				continue;
 			}
 			for(int L = 1; L <= last; L++)
-			{ // the children of level L - 1: hit records of level L, index words of level L - 1
+			{ // the children of level L - 1: hit records of level L, wave headers of level L - 1
 				p.nd_src = nodes(L - 1);
 				p.ns_src = shade(L - 1);
 				p.nd_src_level0 = L == 1;
