@@ -46,3 +46,19 @@ def test_numbers_are_read_like_atoi_and_atof():
 def test_bad_image_size_is_refused_before_anything_is_sized(capsys):
     assert render_cli.main(["--path", "a.scn", "--output", "b.ppm", "--width", "abc"]) == 2
     assert "bad image size" in capsys.readouterr().err
+
+
+def test_the_new_flags_are_off_unless_given():
+    """--strict-scn, --shade-triangles, --legacy-reflect, --progressive K [--progressive-every M], --format: none of them collides with a
+    reference flag, and a command line without them is the reference's."""
+    base = ["--path", "a.scn", "--output", "b.ppm"]
+    o = render_cli._parse(base)
+    assert not any(k in o for k in ("strict_scn", "shade_triangles", "legacy_reflect", "progressive", "progressive_every", "format"))
+    o = render_cli._parse(base + ["--shade-triangles", "--legacy-reflect", "--strict-scn", "--progressive", "8", "--progressive-every", "2", "--format", "pfm"])
+    assert o["shade_triangles"] and o["legacy_reflect"] and o["strict_scn"] and o["progressive"] == 8 and o["progressive_every"] == 2 and o["format"] == "pfm"
+    assert render_cli._parse(base + ["--progressive", "0"])["progressive"] == 1  # (atoi semantics, clamped: one pass is the frame itself)
+
+
+def test_an_unknown_format_is_a_usage_error(capsys):
+    assert render_cli.main(["--path", "a.scn", "--output", "b.ppm", "--format", "exr"]) == 0
+    assert "format takes ppm, png or pfm" in capsys.readouterr().err
