@@ -6,7 +6,7 @@
 // own scene.cpp; the reference's shade() / bp::* / utils.h / parseScene()
 // are therefore the real thing.  Only this container can build it (the GPU
 // box has no /root/reference); its outputs are committed as fixtures under
-// tests/golden/ by tools/make_golden.py.
+// tests/golden/ by tests/golden/make_golden.py.
 //
 // Why a driver instead of the reference's main.cpp: main.cpp:8-9 includes
 // <SDL.h>/<SDL_opengl.h>, SDL2 is not installed in this image, and writing a

@@ -4,7 +4,7 @@ options over every mode the product has (--gillum at random N and depth through 
 --shadow, --strict-scn, --shade-triangles, --legacy-reflect, --progressive), small frames, bit-for-bit comparison of the float image,
 the bytes and the ray / hit / shadow-ray counts.
 
-    python tools/fuzz_parity.py [cases=200] [seed=1]
+    python tests/fuzz_parity.py [cases=200] [seed=1]
 """
 import os
 import sys

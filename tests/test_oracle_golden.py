@@ -1,6 +1,6 @@
 """Pins the oracle: the C restatement in (glibc-replay RNG, libm) mode must be
 byte-identical to PPMs produced by the reference's own shade()/parseScene()
-(tests/golden/ref_*.ppm.gz, made by tools/make_golden.py with oracle/_ref) and
+(tests/golden/ref_*.ppm.gz, made by tests/golden/make_golden.py with oracle/_ref) and
 to the reference's own fixture renders/testcpu.ppm.  CPU only."""
 import gzip
 import os
