@@ -283,8 +283,16 @@ SKR_DEV Activated activate_record(const SceneView &sv, const RenderParams &p, bo
 	return a;
 }
 
+#ifndef SKR_SHADE_WAVES
+#define SKR_SHADE_WAVES 5 // waves per SIMD the record-shading kernels are held to (0: whatever their registers allow: 102 VGPRs, 4 waves; at 5 a 1/8 headline share takes 0.290 instead of 0.298 ms, at 6 0.296)
+#endif
+#if SKR_SHADE_WAVES
+#define SKR_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(SKR_SHADE_WAVES, SKR_SHADE_WAVES)))
+#else
+#define SKR_SHADE_ATTR
+#endif
 template <bool TRIS>
-__global__ __launch_bounds__(256) void skr_activate_kernel(const RenderParams p)
+__global__ __launch_bounds__(256) SKR_SHADE_ATTR void skr_activate_kernel(const RenderParams p)
 { // a workgroup covers 256 consecutive positions of one region; positions past the region's count exit
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(256) void skr_activate_kernel(const RenderParams p)
 // arithmetic of leaf_batch() below, on records instead of ring entries.  Dense numbering through the level's prefix sums
 // (region_prefix): position i belongs to the region whose prefix range holds it.
 template <bool TRIS>
-__global__ __launch_bounds__(256) void skr_shade_leaf_kernel(const RenderParams p)
+__global__ __launch_bounds__(256) SKR_SHADE_ATTR void skr_shade_leaf_kernel(const RenderParams p)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);

@@ -805,8 +805,16 @@ namespace {
 } // namespace
 
 // One workgroup = a 16x16 pixel block, one lane per pixel.  TRIS = false: no triangles in the scene, the walk is compiled out.
+#ifndef SKR_PRIMARY_WAVES
+#define SKR_PRIMARY_WAVES 0 // waves per SIMD the primary kernel is held to (0: whatever its registers allow) — A/B builds
+#endif
+#if SKR_PRIMARY_WAVES
+#define SKR_PRIMARY_ATTR __attribute__((amdgpu_waves_per_eu(SKR_PRIMARY_WAVES, SKR_PRIMARY_WAVES)))
+#else
+#define SKR_PRIMARY_ATTR
+#endif
 template <bool TRIS>
-__global__ __launch_bounds__(256) void skr_primary_kernel(const RenderParams p)
+__global__ __launch_bounds__(256) SKR_PRIMARY_ATTR void skr_primary_kernel(const RenderParams p)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
