@@ -814,7 +814,7 @@ constexpr int SKR_NODE_LEVELS_MAX = 33;
 #define SKR_TRACE_GRID_MAX 49152u // workgroups of skr_trace_kernel at most (it strides over the blocks of 256 pairs)
 #endif
 #ifndef SKR_FLAT_BELOW
-#define SKR_FLAT_BELOW 1.2e8 // last-level rays (worst case) below which a launch takes the flat schedule: tools/ab_nodes.py, DESIGN.md 5.0n
+#define SKR_FLAT_BELOW 1.2e7 // worst-case records of the last-but-one level (W x rows x N^(depth-2): what the persistent kernel cuts into units of 64 for its 4096 waves) below which a launch takes the flat schedule — a quarter of the headline frame: 0.83e7, a half: 1.66e7: tools/ab_nodes.py, tools/ab_flat.py, DESIGN.md 5.0n
 #endif
 struct NodePlan {
 	bool flat = false;       // the flat schedule (below): the leaves' hits are a record level of their own
@@ -829,17 +829,18 @@ static uint32_t *lc_prefix_host(uint32_t *ctr) { return ctr + SKR_PULL_STRIDE * 
 static const uint32_t LEAF2_GRID = 256u * SKR_LEAF2_OCC;                   // every workgroup resident: 256 CUs x 4 workgroups of 4 waves
 static const size_t LVL_CTR_WORDS = (size_t) SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS + 2u); // counts, taken, mask, prefix
 
-// Small launches (one rank's share of a frame cut over many GPUs) take the FLAT schedule: the last level too is traced by
-// skr_trace_kernel into records, which skr_shade_leaf_kernel shades — every kernel a plain grid, nothing persistent.  The
-// persistent leaf kernel has one or two units per wave on such a launch and ends a whole unit after its queues run dry
-// (a 1/8 headline frame: 66 % busy); on a full frame its ring and windows save the records' 1.2 GB of HBM traffic instead.
-// SKR_FLAT=1 / 0 forces one or the other (A/B runs).
+// Small launches (a rank's share of a frame cut over 4 or 8 GPUs; a full frame with a small tree) take the FLAT schedule: the last
+// level too is traced by skr_trace_kernel into records, which skr_shade_leaf_kernel shades — every kernel a plain grid, nothing
+// persistent.  The persistent leaf kernel has a few units per wave on such a launch and ends a whole unit after its queues run
+// dry (a 1/8 headline frame: 66 % busy); on a large launch its ring and windows save the records' 1.2 GB of HBM traffic instead.
+// The measure is the persistent kernel's own: how many records it would cut into units (worst case).  SKR_FLAT=1 / 0 forces one
+// or the other (A/B runs; tools/ab_flat.py shows the rule picking the faster schedule on a spread of configurations).
 static bool nodes_flat_wanted(const RenderParams &p)
 {
 	if(p.sw.flat) return p.sw.flat > 0;
-	double rays = (double) p.width * p.out_rows; // rays of the last level if every ray hit
-	for(int k = 1; k < p.max_depth; k++) rays *= (double) p.num_path_traces;
-	return rays < SKR_FLAT_BELOW;
+	double recs = (double) p.width * p.out_rows; // records the persistent kernel would cut into its units, if every ray hit
+	for(int k = 2; k < p.max_depth; k++) recs *= (double) p.num_path_traces;
+	return recs < SKR_FLAT_BELOW;
 }
 
 static bool plan_for(const RenderParams &p, uint32_t nblk, bool flat, NodePlan &pl)
@@ -887,16 +888,17 @@ static bool plan_for(const RenderParams &p, uint32_t nblk, bool flat, NodePlan &
 	return true;
 }
 
-static uint64_t nodes_budget(const RenderParams &p)
-{
-	return p.sw.budget_mb ? (uint64_t) p.sw.budget_mb << 20 : 4ull << 30; // (tests force several bands with a small budget)
+static uint64_t nodes_budget(const RenderParams &p, bool flat)
+{ // (tests force several bands with a small budget.)  The flat schedule runs in one piece or not at all, and its tables are its price:
+  // 4.6 GB for a quarter of the headline frame, of 288
+	return p.sw.budget_mb ? (uint64_t) p.sw.budget_mb << 20 : (flat ? 8ull : 4ull) << 30;
 }
 
 // the largest band (in 16x16 pixel blocks) whose worst-case tables fit the budget; false: not even one block does
 static bool plan_bands(const RenderParams &p, bool flat, NodePlan &pl)
 {
 	const uint32_t bx = (uint32_t) (p.width + 15) / 16, by = (p.out_rows + 15) / 16;
-	const uint64_t budget = nodes_budget(p);
+	const uint64_t budget = nodes_budget(p, flat);
 	uint32_t lo = 1, hi = bx * by;
 	if(!plan_for(p, lo, flat, pl) || pl.banded > budget) return false;
 	if(plan_for(p, hi, flat, pl) && pl.banded <= budget) return true;
