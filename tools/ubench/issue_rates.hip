@@ -105,6 +105,17 @@ __global__ __launch_bounds__(256) void k(unsigned long long *out, float seed)
 			REP16(X)
 #undef X
 			asm volatile("s_waitcnt lgkmcnt(0)");
+		} else if(OP == 19) { // wave-uniform 16-byte loads through the scalar cache: how the triangle walk reads its triangles (shade_common.h)
+			typedef unsigned v4u __attribute__((ext_vector_type(4)));
+			v4u sq0, sq1, sq2, sq3;
+#define X(i) asm volatile("s_load_dwordx4 %0, %1, 0x" #i "0" : "=s"(i & 2 ? (i & 1 ? sq3 : sq2) : (i & 1 ? sq1 : sq0)) : "s"(out));
+			X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9)
+#undef X
+#define X(i) asm volatile("s_load_dwordx4 %0, %1, 0x" #i "0" : "=s"(sq0) : "s"(out));
+			X(a) X(b) X(c) X(d) X(e) X(f)
+#undef X
+			asm volatile("s_waitcnt lgkmcnt(0)");
+			asm volatile("" : : "s"(sq0), "s"(sq1), "s"(sq2), "s"(sq3));
 		}
 	}
 	const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -168,6 +179,7 @@ int main()
 	run<17>("v_readlane_b32");
 	run<7>("ds_bpermute_b32");
 	run<8>("ds_read_b128 bc");
+	run<19>("s_load_dwordx4");
 	run<18>("ds_write_b32");
 	return 0;
 }
