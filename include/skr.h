@@ -263,7 +263,9 @@ const char *skr_kernel_variant(void);  /* name of the kernel the last render lau
 /* Device-side evaluation of the arithmetic spec for unit tests: op selects
  * 0 philox(ctr4,key2 -> out4 u32), 1 sincos(phi -> s,c), 2 powf(x,p),
  * 3 smallest_root(a,b,c), 4 triangle test (o,d,v0,v1,v2 -> hit,t),
- * 5 quantise(c -> u8 as u32), 6 basis(n -> nt,nb), 7 (a,b -> sqrtf(a), a/b).  in/out are DEVICE pointers
+ * 5 quantise(c -> u8 as u32), 6 basis(n -> nt,nb), 7 (a,b -> sqrtf(a), a/b), 8 philox at 10 rounds (op 0: the 7 the draws use),
+ * 9 (hi16 -> mismatch counts of the short exact sqrt, 1/x, x/pi, x/pdf forms against the correctly rounded expansions over the
+ * 65536 binary32 values with those high 16 bits).  in/out are DEVICE pointers
  * to n records of the op's input/output width in 32-bit words. */
 int skr_debug_eval(int op, const void *d_in, void *d_out, uint32_t n, void *stream);
 

@@ -81,6 +81,8 @@ def lib():
         L.sko_render.argtypes = [C.POINTER(Scene), C.POINTER(Options), C.c_void_p, C.c_void_p, C.c_void_p]
         L.sko_render.restype = C.c_int
         L.sko_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.sko_philox4x32_spec.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.sko_philox4x32_r.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32)]
         L.sko_sincos_shared.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.sko_powf_shared.argtypes = [C.c_float, C.c_float]
         L.sko_powf_shared.restype = C.c_float

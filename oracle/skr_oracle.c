@@ -18,11 +18,11 @@
  * The GPU cannot replay glibc rand() in DFS order, so the product defines a
  * second, order-independent semantic that differs from the above ONLY in where
  * random numbers and three libm calls come from:
- *   SKO_RNG_COUNTER  r = float(k)/2^31 with k = 31 bits of Philox4x32-10 keyed by
+ *   SKO_RNG_COUNTER  r = float(k)/2^31 with k = 31 bits of Philox4x32-7 keyed by
  *                    (seed; pixel, aa sample, parent node id, child pair)
  *                    instead of float(rand())/float(RAND_MAX)
- *   SKO_MATH_SHARED  sinf/cosf(2*pi*r2) and powf(x, phong) evaluated by the
- *                    double-precision recipes below (identical operation
+ *   SKO_MATH_SHARED  sinf/cosf(2*pi*r2) evaluated by the binary32 recipe and powf(x, phong)
+ *                    by the binary64 recipe below (identical operation
  *                    sequences exist in the HIP kernel); powf(x,2) == x*x.
  * That mode is what the HIP kernel is compared with, bit for bit.
  *
@@ -65,14 +65,19 @@ static inline v3 vnormalize(v3 v) { return vscale(v, 1.0f / sqrtf(vsqr(v))); }
 /* std::max(0.0f, x) == (0.0f < x) ? x : 0.0f ; NaN -> 0 */
 static inline float max0(float x) { return (0.0f < x) ? x : 0.0f; }
 
-/* ---------------------------------------------------------- Philox4x32-10 */
+/* ------------------------------------------------------------ Philox4x32-R */
 /* Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3"
- * (SC'11).  Known-answer vectors in tests/test_spec_units.py. */
-void sko_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+ * (SC'11).  The counter RNG of the product draws from Philox4x32-7 (SKO_PHILOX_ROUNDS): seven rounds is the
+ * smallest count that passes BigCrush in the paper ("Philox4x32-7 ... Crush-resistant"; ten, the paper's default and
+ * this build's choice through round 2, adds a safety margin); Random123 ships it as philox4x32_R(7, ...).
+ * This is the product's own choice (the reference draws rand(), raytrace.h:119-120): the statistical pin against the
+ * reference's frames is tests/test_statistics.py.  Known-answer vectors of Random123 for 7 AND 10 rounds are asserted
+ * in tests/test_spec_units.py and, on the device, tests/test_gpu_units.py. */
+void sko_philox4x32_r(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4])
 {
 	uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
 	uint32_t k0 = key[0], k1 = key[1];
-	for(int r = 0; r < 10; r++)
+	for(int r = 0; r < rounds; r++)
 	{
 		uint64_t p0 = (uint64_t) 0xD2511F53u * c0;
 		uint64_t p1 = (uint64_t) 0xCD9E8D57u * c2;
@@ -86,6 +91,8 @@ void sko_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 	}
 	out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+void sko_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { sko_philox4x32_r(ctr, key, 10, out); }
+void sko_philox4x32_spec(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { sko_philox4x32_r(ctr, key, SKO_PHILOX_ROUNDS, out); }
 
 /* Counter layout (DESIGN.md "RNG"):
  *   key = (seed lo, seed hi)
@@ -100,7 +107,7 @@ static inline float u31(uint32_t w) { return (float) (w >> 1) / 2147483648.0f; }
 void sko_counter_draws(uint64_t seed, uint32_t pixel, uint32_t aa, uint32_t parent_node, uint32_t child, float *r1, float *r2)
 {
 	uint32_t ctr[4] = {pixel, aa, parent_node, child >> 1}, key[2] = {(uint32_t) seed, (uint32_t) (seed >> 32)}, o[4];
-	sko_philox4x32_10(ctr, key, o);
+	sko_philox4x32_spec(ctr, key, o);
 	*r1 = u31(o[2 * (child & 1)]);
 	*r2 = u31(o[2 * (child & 1) + 1]);
 }
@@ -108,7 +115,7 @@ void sko_counter_draws(uint64_t seed, uint32_t pixel, uint32_t aa, uint32_t pare
 float sko_counter_jitter(uint64_t seed, uint32_t pixel, uint32_t aa)
 {
 	uint32_t ctr[4] = {pixel, aa, 0, 0xFFFFFFFFu}, key[2] = {(uint32_t) seed, (uint32_t) (seed >> 32)}, o[4];
-	sko_philox4x32_10(ctr, key, o);
+	sko_philox4x32_spec(ctr, key, o);
 	return u31(o[0]);
 }
 
@@ -117,40 +124,42 @@ float sko_counter_jitter(uint64_t seed, uint32_t pixel, uint32_t aa)
 static inline double as_double(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
 static inline uint64_t as_u64(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
 
-/* sin/cos of a float angle, evaluated in binary64 and rounded once.
- * k = rint(x*2/pi); y = x - k*pi/2 (two-term Cody-Waite, fma); Taylor
- * polynomials in y^2 (Horner with fma), quadrant select on k&3. */
+/* sin/cos of a binary32 angle in binary32 arithmetic (round 3; rounds 1-2 evaluated them in binary64 and rounded once:
+ * 21 binary64 instructions per ray on the device for digits nothing downstream can see).  The reference calls libm's
+ * cosf/sinf(phi) (raytrace.h:26-27); this is the product's replacement, identical operation for operation in
+ * csrc/device_math.h sincos_spec (packed there for two sibling rays):
+ *   k = rint(phi * 2/pi);  y = ((phi - k*C1) - k*C2) - k*C3  (three-term Cody-Waite, one fma each; the first is exact
+ *   for |phi| <= 8);  odd / even minimax polynomials in z = y*y (Horner, fma);  quadrant select on k & 3.
+ * Every step is a single IEEE binary32 operation (fmaf = one rounding), so x86 and gfx950 produce the same bits.
+ * Accuracy, measured EXHAUSTIVELY over the 1 086 918 620 floats of [0, 2 pi] against correctly rounded values
+ * (tools/sincos_exhaustive.c, profiles/r03_sincos_exhaustive.txt): max error 1.43 ulp (sin), 1.43 ulp (cos); 99.996 % of
+ * the results within 1 ulp.  phi = 2 pi r2 lies in [0, 2 pi]; beyond |phi| ~ 1e4 the reduction loses accuracy (never
+ * reached: r2 is a draw from [0, 1]). */
 void sko_sincos_shared(float phi, float *s, float *c)
 {
-	const double TWO_OVER_PI = 0x1.45F306DC9C883p-1;
-	const double PIO2_HI = 0x1.921FB544p+0;          /* 33 significant bits of pi/2 */
-	const double PIO2_LO = 0x1.0B4611A626331p-34;    /* pi/2 - PIO2_HI */
-	double x = (double) phi;
-	double kd = rint(x * TWO_OVER_PI);
-	int k = (int) kd;
-	double y = fma(-kd, PIO2_HI, x);
-	y = fma(-kd, PIO2_LO, y);
-	double z = y * y;
-	/* sin(y) = y + y*z*(-1/3! + z*(1/5! + ... - z/15!)) */
-	double ps = -1.0 / 1307674368000.0;
-	ps = fma(ps, z, 1.0 / 6227020800.0);
-	ps = fma(ps, z, -1.0 / 39916800.0);
-	ps = fma(ps, z, 1.0 / 362880.0);
-	ps = fma(ps, z, -1.0 / 5040.0);
-	ps = fma(ps, z, 1.0 / 120.0);
-	ps = fma(ps, z, -1.0 / 6.0);
-	double sy = fma(y * z, ps, y);
-	/* cos(y) = 1 + z*(-1/2! + z*(1/4! + ... + z/16!)) */
-	double pc = 1.0 / 20922789888000.0;
-	pc = fma(pc, z, -1.0 / 87178291200.0);
-	pc = fma(pc, z, 1.0 / 479001600.0);
-	pc = fma(pc, z, -1.0 / 3628800.0);
-	pc = fma(pc, z, 1.0 / 40320.0);
-	pc = fma(pc, z, -1.0 / 720.0);
-	pc = fma(pc, z, 1.0 / 24.0);
-	pc = fma(pc, z, -0.5);
-	double cy = fma(z, pc, 1.0);
-	double sv, cv;
+	const float TWO_OVER_PI = 0x1.45f306p-1f;
+	const float PIO2_1 = 0x1.921fb6p+0f;    /* pi/2 rounded to binary32 */
+	const float PIO2_2 = -0x1.777a5cp-25f;  /* pi/2 - PIO2_1, rounded */
+	const float PIO2_3 = -0x1.ee59dap-50f;  /* pi/2 - PIO2_1 - PIO2_2, rounded */
+	const float kf = rintf(phi * TWO_OVER_PI);
+	const int k = (int) kf;
+	float y = fmaf(-kf, PIO2_1, phi);
+	y = fmaf(-kf, PIO2_2, y);
+	y = fmaf(-kf, PIO2_3, y);
+	const float z = y * y, yz = y * z;
+	/* sin(y) = y + y z (S1 + z (S2 + z (S3 + z S4))) on |y| <= pi/4 */
+	float ps = 0x1.66997ap-19f;
+	ps = fmaf(ps, z, -0x1.9ff9bcp-13f);
+	ps = fmaf(ps, z, 0x1.1110f8p-7f);
+	ps = fmaf(ps, z, -0x1.555556p-3f);
+	const float sy = fmaf(yz, ps, y);
+	/* cos(y) = 1 + z (-1/2 + z (C2 + z (C3 + z C4))) */
+	float pc = 0x1.9a52ccp-16f;
+	pc = fmaf(pc, z, -0x1.6c0db0p-10f);
+	pc = fmaf(pc, z, 0x1.55554cp-5f);
+	pc = fmaf(pc, z, -0.5f);
+	const float cy = fmaf(z, pc, 1.0f);
+	float sv, cv;
 	switch(k & 3)
 	{
 		case 0: sv = sy; cv = cy; break;
@@ -158,8 +167,8 @@ void sko_sincos_shared(float phi, float *s, float *c)
 		case 2: sv = -sy; cv = -cy; break;
 		default: sv = -cy; cv = sy; break;
 	}
-	*s = (float) sv;
-	*c = (float) cv;
+	*s = sv;
+	*c = cv;
 }
 
 /* powf(x, p) for x >= 0 (x is max(0, N.H), blinn_phong.h:117), evaluated in

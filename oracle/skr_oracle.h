@@ -103,7 +103,10 @@ int sko_render(const sko_scene *scene, const sko_options *opt, uint8_t *rgb, flo
 
 /* Spec functions exposed for unit tests (tests compare the device
  * implementations against these on the same inputs). */
-void sko_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+#define SKO_PHILOX_ROUNDS 7
+void sko_philox4x32_r(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]);
+void sko_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);   /* (known-answer tests of the round function) */
+void sko_philox4x32_spec(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]); /* SKO_PHILOX_ROUNDS rounds: what the draws use */
 void sko_sincos_shared(float phi, float *s, float *c);
 float sko_powf_shared(float x, float p);
 float sko_smallest_root(float a, float b, float c);

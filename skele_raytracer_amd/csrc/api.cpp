@@ -698,7 +698,7 @@ const char *skr_kernel_variant(void) { return g_variant; }
 
 int skr_debug_eval(int op, const void *d_in, void *d_out, uint32_t n, void *stream)
 {
-	if(!d_in || !d_out || op < 0 || op > 7) return SKR_ERR_ARG;
+	if(!d_in || !d_out || op < 0 || op > 15) return SKR_ERR_ARG;
 	if(n == 0) return SKR_OK;
 	SKR_HIP(skr_launch_debug(op, d_in, d_out, n, (hipStream_t) stream));
 	return SKR_OK;

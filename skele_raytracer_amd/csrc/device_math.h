@@ -30,8 +30,43 @@ static __device__ unsigned long long skr_diag[32 * 64];
 // Correctly rounded binary32 sqrt and divide.  NOT __fsqrt_rn/__fdiv_rn: in this ROCm's
 // __clang_hip_math.h __fsqrt_rn is __ocml_native_sqrt_f32 (approximate).  Plain sqrtf and `/`
 // are IEEE-correct under -fhip-fp32-correctly-rounded-divide-sqrt (tests/test_gpu_units.py).
-SKR_DEV float sk_sqrtf(float x) { return __builtin_sqrtf(x); }
 SKR_DEV float sk_divf(float a, float b) { return a / b; }
+// The same two results from short sequences wherever those provably return them.  The compiler's expansions above cost 16 (sqrt) and
+// 11 (1/b) VALU instructions: denormal scaling, v_div_scale / v_div_fmas / v_div_fixup.  For an operand in [2^-100, 2^101) one coupled
+// Newton step on the hardware's 1-ulp estimate is already the correctly rounded value:
+//   sqrt(x):  y = v_rsq(x); s = x*y; h = y/2;  s + fma(-s, s, x) * h          1/b:  y = v_rcp(b);  y + fma(-b, y, 1) * y
+// checked against the expansions EXHAUSTIVELY — every one of the 2^32 binary32 inputs, on the device (tools/ubench/exact_ops.hip,
+// profiles/r03_exact_ops.txt; tests/test_gpu_units.py repeats it on every run): the sequences differ only below 2^-102 (sqrt) and
+// for denormal operands / results (1/b: biased exponent 0, 253, 254), so anything outside [2^-100, 2^101) — zero, denormals, huge
+// values, infinities, NaN, negative x — takes the expansion.  SKR_FAST_EXACT=0 restores the expansions everywhere (A/B builds).
+#ifndef SKR_FAST_EXACT
+#define SKR_FAST_EXACT 1
+#endif
+SKR_DEV bool mid_range_pos(float x) { return __float_as_uint(x) - (27u << 23) < (201u << 23); }                // 2^-100 <= x < 2^101
+SKR_DEV bool mid_range_abs(float x) { return (__float_as_uint(x) << 1) - (27u << 24) < (201u << 24); }         // 2^-100 <= |x| < 2^101
+SKR_DEV float sk_sqrtf(float x)
+{
+#if SKR_FAST_EXACT
+	if(__builtin_expect(mid_range_pos(x), 1))
+	{
+		const float y = __builtin_amdgcn_rsqf(x);
+		const float s = x * y, h = 0.5f * y;
+		return __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
+	}
+#endif
+	return __builtin_sqrtf(x);
+}
+SKR_DEV float sk_rcpf(float b)
+{ // 1.0f / b
+#if SKR_FAST_EXACT
+	if(__builtin_expect(mid_range_abs(b), 1))
+	{
+		const float y = __builtin_amdgcn_rcpf(b);
+		return __builtin_fmaf(__builtin_fmaf(-b, y, 1.0f), y, y);
+	}
+#endif
+	return 1.0f / b;
+}
 
 SKR_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
 SKR_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -47,18 +82,56 @@ SKR_DEV f3 cross3(f3 x, f3 y) { return mk3(x.y * y.z - y.y * x.z, x.z * y.x - y.
 SKR_DEV float sqr3(f3 v) { return (v.x * v.x + v.y * v.y) + v.z * v.z; }
 SKR_DEV float length3(f3 v) { return sk_sqrtf(sqr3(v)); }
 // glm::normalize: v * (1.0f / sqrt(sum)) (func_geometric.inl:253-261, func_exponential.inl:226-229)
-SKR_DEV f3 normalize3(f3 v) { return v * sk_divf(1.0f, sk_sqrtf(sqr3(v))); }
+SKR_DEV f3 normalize3(f3 v) { return v * sk_rcpf(sk_sqrtf(sqr3(v))); }
 // std::max(0.0f, x): NaN -> 0
 SKR_DEV float max0(float x) { return (0.0f < x) ? x : 0.0f; }
 SKR_DEV f3 ld3(const float4 v) { return mk3(v.x, v.y, v.z); }
 
+// ---------------------------------------------- division by a constant ----
+// v / d for the two divisors the integrator divides by again and again: pi (raytrace.h:213 `direct_diffuse / float(M_PI)`) and
+// pdf = float(1 / pi) (:130 `... / pdf`).  The compiler's correctly rounded `/` costs 10-12 VALU instructions per component; with
+// zh = RN(1/d), zl = RN(1/d - zh) the two-instruction form  fma(x, zh, x * zl)  returns the SAME BITS as x / d for every binary32
+// x that is zero, infinite, NaN or at least 2^-100 in magnitude — checked EXHAUSTIVELY over all 2^32 x for both divisors, on the
+// CPU (tools/constdiv_exhaustive.c, profiles/r03_constdiv_exhaustive.txt) and on the device (tests/test_gpu_units.py); below
+// 2^-100 the product x * zl starts to lose bits to underflow, so lanes holding such a component take the division itself.
+struct ConstDiv { float d, zh, zl; };
+#define SKR_DIV_PI  ConstDiv{0x1.921fb6p+1f, 0x1.45f306p-2f, 0x1.11be6cp-28f}   // d = float(M_PI)
+#define SKR_DIV_PDF ConstDiv{0x1.45f306p-2f, 0x1.921fb6p+1f, 0x1.51b7ccp-25f}   // d = float(1 / M_PI)
+#ifndef SKR_FAST_CONSTDIV
+#define SKR_FAST_CONSTDIV 1 // 0: the plain divisions (A/B builds)
+#endif
+SKR_DEV uint32_t tiny_key(float x) { return (__float_as_uint(x) << 1) - 1u; } // >= (27 << 24) - 1 iff x == 0 or |x| >= 2^-100 (or inf / NaN)
+SKR_DEV f3 div3_const(f3 v, const ConstDiv k)
+{
+#if SKR_FAST_CONSTDIV
+	const uint32_t a = tiny_key(v.x), b = tiny_key(v.y), c = tiny_key(v.z);
+	const uint32_t m = (a < b ? a : b) < c ? (a < b ? a : b) : c;
+	if(__builtin_expect(m >= (27u << 24) - 1u, 1))
+		return mk3(__builtin_fmaf(v.x, k.zh, v.x * k.zl), __builtin_fmaf(v.y, k.zh, v.y * k.zl), __builtin_fmaf(v.z, k.zh, v.z * k.zl));
+#endif
+	return mk3(sk_divf(v.x, k.d), sk_divf(v.y, k.d), sk_divf(v.z, k.d));
+}
+SKR_DEV float div_const(float x, const ConstDiv k)
+{
+#if SKR_FAST_CONSTDIV
+	if(__builtin_expect(tiny_key(x) >= (27u << 24) - 1u, 1)) return __builtin_fmaf(x, k.zh, x * k.zl);
+#endif
+	return sk_divf(x, k.d);
+}
+
 // ---------------------------------------------------------------- RNG ----
-// Philox4x32-10 (Salmon et al., SC'11).  One call yields the (r1, r2) pairs of
-// two sibling GI rays.
-SKR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+// Philox4x32-R (Salmon et al., SC'11).  One call yields the (r1, r2) pairs of two sibling GI rays.  The product draws from
+// SKR_PHILOX_ROUNDS = 7 rounds, the smallest count that passes BigCrush in the paper (10, this build's choice through round 2, is
+// the paper's default with a safety margin): 30 of the 100 VALU instructions of a call, once per leaf round.  The CPU checker of the
+// test suite carries the same constant; tests assert Random123's known-answer vectors for 7 and for 10 rounds on both sides.
+#ifndef SKR_PHILOX_ROUNDS
+#define SKR_PHILOX_ROUNDS 7
+#endif
+template <int ROUNDS>
+SKR_DEV void philox4x32_r(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
 {
 #pragma unroll
-	for(int r = 0; r < 10; r++)
+	for(int r = 0; r < ROUNDS; r++)
 	{
 		// one widening multiply per product (v_mad_u64_u32) instead of a mul_hi + mul_lo pair: integer multiplies
 		// issue at quarter rate on CDNA, and this function is ~10 % of a leaf round
@@ -78,58 +151,59 @@ SKR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
 	out[2] = c2;
 	out[3] = c3;
 }
+// the counter RNG of the product (DESIGN.md "Counter RNG")
+SKR_DEV void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+	philox4x32_r<SKR_PHILOX_ROUNDS>(c0, c1, c2, c3, k0, k1, out);
+}
 
 // float(k) / float(RAND_MAX) with k = 31 random bits: the map the reference
 // applies to rand() (raytrace.h:119-120, main.cpp:146); float(RAND_MAX) == 2^31.
 SKR_DEV float u31_to_unit(uint32_t w) { return (float) (w >> 1) * 4.656612873077392578125e-10f; } // * 2^-31 is exact
 
 // ------------------------------------------------------- shared math ----
-// sin/cos of a binary32 angle evaluated in binary64, rounded once.
-// Its only caller, gi_direction(), is kept out of line: inlined, the binary64 polynomial constants stay
-// live across the callers' loops and cost ~40 VGPRs of pressure everywhere.
-// fma(a, b, K) with the wave-uniform constant K held in a scalar register pair: v_fma_f64 takes it as its SGPR operand.
-// (Left to itself the compiler materialises every coefficient of the two polynomials below in a VGPR pair in front of
-// a v_fmac_f64: 33 v_mov per call, a quarter of the function.)
-SKR_DEV double fma_k(double a, double b, double k)
+typedef float f2 __attribute__((ext_vector_type(2)));
+SKR_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); } // v_pk_fma_f32: two IEEE fmaf
+SKR_DEV f2 splat2(float v) { return f2{v, v}; }
+
+// sin/cos of a binary32 angle in binary32 arithmetic: operation for operation what the CPU checker of the test suite does (round 3; through round 2
+// both were evaluated in binary64: 21 binary64 instructions per ray).  k = rint(phi * 2/pi); three-term Cody-Waite reduction (one
+// fma each); minimax polynomials in z = y*y (Horner, fma); quadrant by a select and a sign flip each.  Every step is one IEEE
+// binary32 operation, so host and device agree bit for bit; max error 1.43 ulp over every float of [0, 2 pi] (exhaustive,
+// tools/sincos_exhaustive.c).  Written for TWO angles at once — the sibling rays of a pair — in packed arithmetic; each component
+// is exactly what the one-angle form computes.
+SKR_DEV void sincos_spec2(f2 phi, f2 &s, f2 &c)
 {
-	asm("" : "+s"(k));
-	return __builtin_fma(a, b, k);
+	f2 kf = phi * 0x1.45f306p-1f;
+	kf = f2{__builtin_rintf(kf.x), __builtin_rintf(kf.y)};
+	const f2 nk = -kf;
+	f2 y = fma2(nk, splat2(0x1.921fb6p+0f), phi);
+	y = fma2(nk, splat2(-0x1.777a5cp-25f), y);
+	y = fma2(nk, splat2(-0x1.ee59dap-50f), y);
+	const f2 z = y * y, yz = y * z;
+	f2 ps = splat2(0x1.66997ap-19f);
+	ps = fma2(ps, z, splat2(-0x1.9ff9bcp-13f));
+	ps = fma2(ps, z, splat2(0x1.1110f8p-7f));
+	ps = fma2(ps, z, splat2(-0x1.555556p-3f));
+	const f2 sy = fma2(yz, ps, y);
+	f2 pc = splat2(0x1.9a52ccp-16f);
+	pc = fma2(pc, z, splat2(-0x1.6c0db0p-10f));
+	pc = fma2(pc, z, splat2(0x1.55554cp-5f));
+	pc = fma2(pc, z, splat2(-0.5f));
+	const f2 cy = fma2(z, pc, splat2(1.0f));
+	// quadrant k mod 4: (s, c) = (sy, cy), (cy, -sy), (-sy, -cy), (-cy, sy)
+	const uint32_t q0 = (uint32_t) (int) kf.x, q1 = (uint32_t) (int) kf.y;
+	const bool sw0 = q0 & 1u, sw1 = q1 & 1u;
+	s = f2{__uint_as_float(__float_as_uint(sw0 ? cy.x : sy.x) ^ ((q0 & 2u) << 30)), __uint_as_float(__float_as_uint(sw1 ? cy.y : sy.y) ^ ((q1 & 2u) << 30))};
+	c = f2{__uint_as_float(__float_as_uint(sw0 ? sy.x : cy.x) ^ (((q0 + 1u) & 2u) << 30)), __uint_as_float(__float_as_uint(sw1 ? sy.y : cy.y) ^ (((q1 + 1u) & 2u) << 30))};
 }
 
 SKR_DEV void sincos_spec(float phi, float &s, float &c)
 {
-	const double x = (double) phi;
-	const double kd = rint(x * 0x1.45F306DC9C883p-1); // 2/pi
-	const int k = (int) kd;
-	double y = fma(-kd, 0x1.921FB544p+0, x);        // pi/2 high 33 bits
-	y = fma(-kd, 0x1.0B4611A626331p-34, y);         // pi/2 low
-	const double z = y * y;
-	double ps = -1.0 / 1307674368000.0;
-	ps = fma_k(ps, z, 1.0 / 6227020800.0);
-	ps = fma_k(ps, z, -1.0 / 39916800.0);
-	ps = fma_k(ps, z, 1.0 / 362880.0);
-	ps = fma_k(ps, z, -1.0 / 5040.0);
-	ps = fma_k(ps, z, 1.0 / 120.0);
-	ps = fma_k(ps, z, -1.0 / 6.0);
-	const double sy = fma(y * z, ps, y);
-	double pc = 1.0 / 20922789888000.0;
-	pc = fma_k(pc, z, -1.0 / 87178291200.0);
-	pc = fma_k(pc, z, 1.0 / 479001600.0);
-	pc = fma_k(pc, z, -1.0 / 3628800.0);
-	pc = fma_k(pc, z, 1.0 / 40320.0);
-	pc = fma_k(pc, z, -1.0 / 720.0);
-	pc = fma_k(pc, z, 1.0 / 24.0);
-	pc = fma_k(pc, z, -0.5);
-	const double cy = fma_k(z, pc, 1.0);
-	// quadrant k mod 4: (s, c) = (sy, cy), (cy, -sy), (-sy, -cy), (-cy, sy).  Rounding to binary32 commutes with the swap and
-	// with negation (round-to-nearest-even is symmetric), so both are done on the two rounded floats: a select and a
-	// sign-bit flip each instead of three 64-bit selects each.
-	const float sf = (float) sy, cf = (float) cy;
-	const uint32_t q = (uint32_t) k;
-	const bool swap = q & 1u;
-	const uint32_t s_sign = (q & 2u) << 30, c_sign = ((q + 1u) & 2u) << 30;
-	s = __uint_as_float(__float_as_uint(swap ? cf : sf) ^ s_sign);
-	c = __uint_as_float(__float_as_uint(swap ? sf : cf) ^ c_sign);
+	f2 s2, c2;
+	sincos_spec2(splat2(phi), s2, c2);
+	s = s2.x;
+	c = c2.x;
 }
 
 // General (non-integer exponent) branch of powf_spec: 2^(p log2 x) in binary64.  Cold for every
@@ -301,8 +375,6 @@ SKR_DEV bool bracket_from_ec(f3 e, float c, f3 d, const RayFilt &f, float &lo, f
 // v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 do two IEEE binary32 operations per lane per
 // instruction with the same rounding as the scalar forms, so every component below is the
 // same value sphere_bracket() would produce for that ray alone.
-typedef float f2 __attribute__((ext_vector_type(2)));
-
 struct RayPair {
 	f2 dx, dy, dz;              // directions of ray 0 / ray 1, component-wise
 	f2 two_a, four_a, inv2a, k_err;
@@ -404,7 +476,7 @@ SKR_DEV bool triangle_hit(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float &t)
 	const f3 p = cross3(d, e2);
 	const float det = dot3(e1, p);
 	if(fabsf(det) < 0.00001f) return false;
-	const float inv = sk_divf(1.0f, det);
+	const float inv = sk_rcpf(det);
 	const f3 tv = o - v0;
 	const float u = inv * dot3(mk3(-tv.x, -tv.y, -tv.z), p);
 	if(u < 0 || u > 1) return false;

@@ -46,7 +46,7 @@ SKR_DEV f3 shade(const SceneView &sv, const RenderParams &p, f3 o, f3 d, uint32_
 			uint32_t rnd[4];
 			for(int i = 0; i < p.num_path_traces; i++)
 			{
-				if((i & 1) == 0) philox4x32_10(pixel, aa, node, (uint32_t) i >> 1, p.seed_lo, p.seed_hi, rnd);
+				if((i & 1) == 0) philox4x32(pixel, aa, node, (uint32_t) i >> 1, p.seed_lo, p.seed_hi, rnd);
 				const float r1 = u31_to_unit(rnd[2 * (i & 1)]), r2 = u31_to_unit(rnd[2 * (i & 1) + 1]);
 				const f3 w = gi_direction(r1, r2, N, nt, nb);
 				const f3 child = shade<LEVELS - 1>(sv, p, co, w, node * (uint32_t) p.num_path_traces + (uint32_t) i + 1u, pixel, aa, cn);
@@ -180,7 +180,7 @@ SKR_DEV f3 shade_surfaces(const SceneView &sv, const RenderParams &p, f3 o, f3 d
 			uint32_t rnd[4];
 			for(int i = 0; i < p.num_path_traces; i++)
 			{
-				if((i & 1) == 0) philox4x32_10(pixel, aa, node, (uint32_t) i >> 1, p.seed_lo, p.seed_hi, rnd);
+				if((i & 1) == 0) philox4x32(pixel, aa, node, (uint32_t) i >> 1, p.seed_lo, p.seed_hi, rnd);
 				const float r1 = u31_to_unit(rnd[2 * (i & 1)]), r2 = u31_to_unit(rnd[2 * (i & 1) + 1]);
 				const f3 w = gi_direction(r1, r2, N, nt, nb);
 				const f3 child = shade_surfaces<LEVELS - 1>(sv, p, co, w, node * (uint32_t) p.num_path_traces + (uint32_t) i + 1u, pixel, aa, b.file, cn);
@@ -273,7 +273,7 @@ static __device__ __attribute__((noinline)) f3 shade_legacy(const SceneView &sv,
 			uint32_t rnd[4];
 			for(int i = 0; i < p.num_path_traces; i++)
 			{
-				if((i & 1) == 0) philox4x32_10(pixel, aa, node, (uint32_t) i >> 1, p.seed_lo, p.seed_hi, rnd);
+				if((i & 1) == 0) philox4x32(pixel, aa, node, (uint32_t) i >> 1, p.seed_lo, p.seed_hi, rnd);
 				const float r1 = u31_to_unit(rnd[2 * (i & 1)]), r2 = u31_to_unit(rnd[2 * (i & 1) + 1]);
 				const f3 w = gi_direction(r1, r2, N, nt, nb);
 				const f3 child = shade_legacy<LEVELS - 1>(sv, p, co, w, node * A + (uint32_t) i + 1u, pixel, aa, cn);
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void skr_render_kernel(const RenderParams p)
 			for(int s = 0; s < ns2; s++)
 			{
 				uint32_t rnd[4];
-				philox4x32_10(pixel, (uint32_t) s, 0u, 0xFFFFFFFFu, p.seed_lo, p.seed_hi, rnd);
+				philox4x32(pixel, (uint32_t) s, 0u, 0xFFFFFFFFu, p.seed_lo, p.seed_hi, rnd);
 				const float r = u31_to_unit(rnd[0]);
 				const float u = ((2 * (((float) x + r) * p.inv_width) - 1) * p.angle) * p.aspect;
 				const float v = (1 - 2 * (((float) (int) y + r) * p.inv_height)) * p.angle;
@@ -507,7 +507,29 @@ __global__ void skr_debug_kernel(int op, const uint32_t *in, uint32_t *out, uint
 		case 0: {
 			uint32_t o[4];
 			const uint32_t *c = in + 6 * i;
-			philox4x32_10(c[0], c[1], c[2], c[3], c[4], c[5], o);
+			philox4x32(c[0], c[1], c[2], c[3], c[4], c[5], o);
+			for(int k = 0; k < 4; k++) out[4 * i + k] = o[k];
+			break;
+		}
+		case 9: { // EXHAUSTIVE check of the short exact forms (device_math.h) against the compiler's correctly rounded expansions: record i
+		          // covers the 65536 bit patterns in[i] << 16 ...; out = mismatches of {sk_sqrtf, sk_rcpf, div_const pi, div_const pdf}
+			uint32_t bad[4] = {0, 0, 0, 0};
+			auto same = [](float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); };
+			for(uint32_t k = 0; k < 65536u; k++)
+			{
+				const float x = F((in[i] << 16) | k);
+				bad[0] += !same(sk_sqrtf(x), __builtin_sqrtf(x));
+				bad[1] += !same(sk_rcpf(x), 1.0f / x);
+				bad[2] += !same(div_const(x, SKR_DIV_PI), x / (float) 3.14159265358979323846);
+				bad[3] += !same(div_const(x, SKR_DIV_PDF), x / (float) (1 / 3.14159265358979323846));
+			}
+			for(int k = 0; k < 4; k++) out[4 * i + k] = bad[k];
+			break;
+		}
+		case 8: { // the round function at Random123's default count (known-answer vectors exist for 7 and for 10 rounds)
+			uint32_t o[4];
+			const uint32_t *c = in + 6 * i;
+			philox4x32_r<10>(c[0], c[1], c[2], c[3], c[4], c[5], o);
 			for(int k = 0; k < 4; k++) out[4 * i + k] = o[k];
 			break;
 		}

@@ -159,9 +159,10 @@ __global__ __launch_bounds__(256) SKR_TRACE_ATTR void skr_trace_kernel(const Ren
 		f3 nt, nb;
 		tangent_basis(Nn, nt, nb);
 		uint32_t rnd[4];
-		philox4x32_10(pixel, p.aa_index, node_id, j, p.seed_lo, p.seed_hi, rnd);
+		philox4x32(pixel, p.aa_index, node_id, j, p.seed_lo, p.seed_hi, rnd);
 		const float q1a = u31_to_unit(rnd[0]), q2a = u31_to_unit(rnd[1]), q1b = u31_to_unit(rnd[2]), q2b = u31_to_unit(rnd[3]);
-		const f3 d0 = gi_direction(q1a, q2a, Nn, nt, nb), d1 = gi_direction(q1b, q2b, Nn, nt, nb);
+		const DirPair dp = gi_direction_pair(q1a, q2a, q1b, q2b, Nn, nt, nb);
+		const f3 d0 = dp.d0, d1 = dp.d1;
 		cn.rays += second ? 2u : 1u;
 		const RayPair rp = make_pair(d0, d1);
 		BestState s0, s1;
@@ -335,7 +336,6 @@ __global__ __launch_bounds__(256) SKR_SHADE_ATTR void skr_shade_leaf_kernel(cons
 	const uint32_t total = prefix[64];
 	if((uint32_t) blockIdx.x * 256u >= total) return; // (uniform per workgroup)
 	const SceneView sv = stage_scene(p, lds4, TRIS);
-	const float pdf = (float) (1 / 3.14159265358979323846);
 	Counters cn{0, 0, 0};
 	for(uint32_t base = (uint32_t) blockIdx.x * 256u; base < total; base += gridDim.x * 256u)
 	{
@@ -352,9 +352,9 @@ __global__ __launch_bounds__(256) SKR_SHADE_ATTR void skr_shade_leaf_kernel(cons
 		const Activated a = activate_record(sv, p, act, rec, cn);
 		if(act)
 		{
-			const f3 tot = mk3(0, 0, 0) / (float) p.num_path_traces;
-			const f3 colour = (a.direct / (float) 3.14159265358979323846 + tot * 2.0f) * ld3(sv.kd[a.sph]);
-			store3(p.res_out + (size_t) rec * 3, (colour * a.r1) / pdf);
+			const f3 tot = mk3(0, 0, 0); // (0,0,0) / N with N >= 1 (skr_nodes_supported): +0 in every component, no division needed
+			const f3 colour = (div3_const(a.direct, SKR_DIV_PI) + tot * 2.0f) * ld3(sv.kd[a.sph]);
+			store3(p.res_out + (size_t) rec * 3, div3_const(colour * a.r1, SKR_DIV_PDF));
 		}
 	}
 	add_counters(p, cn, blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63);
@@ -419,9 +419,9 @@ SKR_DEV void leaf_batch(const SceneView &sv, const RenderParams &p, Ring &q, flo
 		const f3 Nn = normalize3(P - ld3(sv.geom[sph]));
 		cn.hits++;
 		const f3 direct = direct_light(sv, p, sph, P, Nn, cn);
-		const f3 total = mk3(0, 0, 0) / (float) p.num_path_traces;
-		const f3 colour = (direct / (float) 3.14159265358979323846 + total * 2.0f) * ld3(sv.kd[sph]);
-		const f3 c = (colour * r1) / (float) (1 / 3.14159265358979323846);
+		const f3 total = mk3(0, 0, 0); // (0,0,0) / N with N >= 1 (skr_nodes_supported): +0 in every component, no division needed
+		const f3 colour = (div3_const(direct, SKR_DIV_PI) + total * 2.0f) * ld3(sv.kd[sph]);
+		const f3 c = div3_const(colour * r1, SKR_DIV_PDF);
 		float *s = slots + (int) ((ids >> 23) & (NWIN - 1)) * WIN_FLOATS + (int) ((ids >> 22) & 1u) * 192 + kl; // [round][child][component][lane]
 		s[0] = c.x;
 		s[64] = c.y;
@@ -479,7 +479,6 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 	Ring q{wbase, 0, 0};
 	float *slots = wbase + NQ_CAP * NQ_F;
 	const int N = p.num_path_traces, PP = (N + 1) >> 1;
-	const float pdf = (float) (1 / 3.14159265358979323846);
 	uint32_t region = g & (SKR_P1_REGIONS - 1u);
 	unsigned long long dead = 0; // regions this wave has seen exhausted
 	// FIRST: the level-0 nodes form virtual regions — unit u of the node array belongs to region u mod 64
@@ -602,15 +601,16 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 			if(act)
 			{
 				uint32_t rnd[4];
-				philox4x32_10(pixel, p.aa_index, node_id, (uint32_t) j, p.seed_lo, p.seed_hi, rnd);
+				philox4x32(pixel, p.aa_index, node_id, (uint32_t) j, p.seed_lo, p.seed_hi, rnd);
 				q1a = u31_to_unit(rnd[0]);
 				q1b = u31_to_unit(rnd[2]);
 				const float q2a = u31_to_unit(rnd[1]), q2b = u31_to_unit(rnd[3]);
 				f3 nq = Nn;
 				asm volatile("" : "+v"(nq.x), "+v"(nq.y), "+v"(nq.z)); // (keeps the next line inside the loop)
 				const f3 nbr = cross3(nq, nt); // (utils.h:164, formed again per round: three registers less to carry)
-				d0 = gi_direction(q1a, q2a, Nn, nt, nbr);
-				d1 = gi_direction(q1b, q2b, Nn, nt, nbr);
+				const DirPair dp = gi_direction_pair(q1a, q2a, q1b, q2b, Nn, nt, nbr);
+				d0 = dp.d0;
+				d1 = dp.d1;
 				cn.rays += second ? 2u : 1u;
 				const RayPair rp = make_pair(d0, d1);
 				BestState s0, s1;
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 				hit0 = classify_child(sv, co, d0, rp.two_a.x, rp.four_a.x, s0, black);
 				if(!hit0)
 				{ // raytrace.h:189-192 / :221-224, then :130: total += (r1 * colour) / pdf
-					const f3 c = ((black ? mk3(0, 0, 0) : p.background) * q1a) / pdf;
+					const f3 c = div3_const((black ? mk3(0, 0, 0) : p.background) * q1a, SKR_DIV_PDF);
 					win[0] = c.x;
 					win[cs] = c.y;
 					win[2 * cs] = c.z;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 					hit1 = classify_child(sv, co, d1, rp.two_a.y, rp.four_a.y, s1, black);
 					if(!hit1)
 					{
-						const f3 c = ((black ? mk3(0, 0, 0) : p.background) * q1b) / pdf;
+						const f3 c = div3_const((black ? mk3(0, 0, 0) : p.background) * q1b, SKR_DIV_PDF);
 						win[3 * cs] = c.x;
 						win[4 * cs] = c.y;
 						win[5 * cs] = c.z;
@@ -690,9 +690,9 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 				sph = __float_as_uint(r1row.y) & 0xffffu;
 			}
 			const f3 total = acc / (float) N;
-			const f3 colour = (direct / (float) 3.14159265358979323846 + total * 2.0f) * ld3(sv.kd[sph]);
+			const f3 colour = (div3_const(direct, SKR_DIV_PI) + total * 2.0f) * ld3(sv.kd[sph]);
 			if(FIRST) emit_sample(p, out_idx, colour);
-			else store3(p.res_out + (size_t) out_idx * 3, (colour * r1) / pdf); // :130, into the parent's sum
+			else store3(p.res_out + (size_t) out_idx * 3, div3_const(colour * r1, SKR_DIV_PDF)); // :130, into the parent's sum
 		}
 		STAMP(5);
 #if defined(SKR_TIMELINE) && SKR_TIMELINE
@@ -728,7 +728,6 @@ __global__ __launch_bounds__(256) void skr_finalize_kernel2(const RenderParams p
 	if((uint32_t) blockIdx.x * 256u >= n) return;
 	if(node >= n) return;
 	const int N = p.num_path_traces, PP = (N + 1) >> 1;
-	const float pdf = (float) (1 / 3.14159265358979323846);
 	const float4 *row = p.ns_src + (size_t) node * 2; // the shading row is all this kernel reads of a node
 	const float4 b0 = row[0], b1 = row[1];
 	const uint32_t pixel = __float_as_uint(b1.z), node_id = __float_as_uint(b1.w);
@@ -777,7 +776,7 @@ __global__ __launch_bounds__(256) void skr_finalize_kernel2(const RenderParams p
 			if(j0 + k < PP)
 			{
 				uint32_t rnd[4]; // the draws the trace kernel made for this pair: r1 of children 2j, 2j+1 (DESIGN.md "RNG")
-				philox4x32_10(pixel, p.aa_index, node_id, (uint32_t) (j0 + k), p.seed_lo, p.seed_hi, rnd);
+				philox4x32(pixel, p.aa_index, node_id, (uint32_t) (j0 + k), p.seed_lo, p.seed_hi, rnd);
 #pragma unroll
 				for(int c = 0; c < 2; c++)
 				{
@@ -787,7 +786,7 @@ __global__ __launch_bounds__(256) void skr_finalize_kernel2(const RenderParams p
 						if(!(code[k] & (c ? PC_HIT1 : PC_HIT0)))
 						{ // raytrace.h:189-192 / :221-224, then :130: (r1 * colour) / pdf; a triangle's (0 * r1) / pdf is +0
 							const float r1 = u31_to_unit(rnd[2 * c]);
-							term = (code[k] & (c ? PC_BLACK1 : PC_BLACK0)) ? mk3(0, 0, 0) : (p.background * r1) / pdf;
+							term = (code[k] & (c ? PC_BLACK1 : PC_BLACK0)) ? mk3(0, 0, 0) : div3_const(p.background * r1, SKR_DIV_PDF);
 						}
 						total = total + term;
 					}
@@ -798,9 +797,9 @@ __global__ __launch_bounds__(256) void skr_finalize_kernel2(const RenderParams p
 	const f3 direct = mk3(b0.x, b0.y, b0.z);
 	const uint32_t sph = __float_as_uint(b0.w);
 	total = total / (float) N;
-	const f3 colour = (direct / (float) 3.14159265358979323846 + total * 2.0f) * ld3(p.sph_kd[sph]); // raytrace.h:213
+	const f3 colour = (div3_const(direct, SKR_DIV_PI) + total * 2.0f) * ld3(p.sph_kd[sph]); // raytrace.h:213
 	if(p.nd_src_level0) emit_sample(p, __float_as_uint(b1.y), colour);
-	else store3(p.res_out + (size_t) __float_as_uint(b1.y) * 3, (colour * b1.x) / pdf);
+	else store3(p.res_out + (size_t) __float_as_uint(b1.y) * 3, div3_const(colour * b1.x, SKR_DIV_PDF));
 }
 
 // =====================================================================================================================

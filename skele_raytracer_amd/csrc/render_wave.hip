@@ -278,7 +278,7 @@ SKR_DEV void child_round(const Wave &w, const ParSrc &par, int kbase, int np, in
 	if(valid)
 	{
 		uint32_t rnd[4];
-		philox4x32_10(pixel, w.aa, node, (uint32_t) i >> 1, w.p->seed_lo, w.p->seed_hi, rnd);
+		philox4x32(pixel, w.aa, node, (uint32_t) i >> 1, w.p->seed_lo, w.p->seed_hi, rnd);
 		const float r1 = (i & 1) ? u31_to_unit(rnd[2]) : u31_to_unit(rnd[0]);
 		const float r2 = (i & 1) ? u31_to_unit(rnd[3]) : u31_to_unit(rnd[1]);
 		const f3 d = gi_direction(r1, r2, N, nt, nb);
@@ -369,11 +369,11 @@ SKR_DEV PairOut child_round_pairs(const Wave &w, const ParSrc &par, int kbase, i
 	if(valid)
 	{
 		uint32_t rnd[4];
-		philox4x32_10(pixel, w.aa, node, (uint32_t) j, w.p->seed_lo, w.p->seed_hi, rnd);
+		philox4x32(pixel, w.aa, node, (uint32_t) j, w.p->seed_lo, w.p->seed_hi, rnd);
 		const float r1a = u31_to_unit(rnd[0]), r2a = u31_to_unit(rnd[1]);
 		const float r1b = u31_to_unit(rnd[2]), r2b = u31_to_unit(rnd[3]);
-		const f3 d0 = gi_direction(r1a, r2a, N, nt, nb);
-		const f3 d1 = gi_direction(r1b, r2b, N, nt, nb);
+		const DirPair dp = gi_direction_pair(r1a, r2a, r1b, r2b, N, nt, nb);
+		const f3 d0 = dp.d0, d1 = dp.d1;
 		cn.rays += second ? 2u : 1u;
 		const RayPair rp = make_pair(d0, d1);
 		BestState s0, s1;
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 		if(p.grid_size > 0)
 		{
 			uint32_t rnd[4];
-			philox4x32_10(pixel, (uint32_t) s, 0u, 0xFFFFFFFFu, p.seed_lo, p.seed_hi, rnd);
+			philox4x32(pixel, (uint32_t) s, 0u, 0xFFFFFFFFu, p.seed_lo, p.seed_hi, rnd);
 			const float r = u31_to_unit(rnd[0]);
 			u = ((2 * (((float) x + r) * p.inv_width) - 1) * p.angle) * p.aspect;
 			v = (1 - 2 * (((float) (int) y + r) * p.inv_height)) * p.angle;
@@ -1176,9 +1176,10 @@ __global__ __launch_bounds__(256) void skr_level1_kernel(const RenderParams p)
 		f3 nt, nb;
 		tangent_basis(Nn, nt, nb);
 		uint32_t rnd[4];
-		philox4x32_10(pixel, p.aa_index, 0u, j, p.seed_lo, p.seed_hi, rnd); // node 0: the children of the primary hit
+		philox4x32(pixel, p.aa_index, 0u, j, p.seed_lo, p.seed_hi, rnd); // node 0: the children of the primary hit
 		const float r1a = u31_to_unit(rnd[0]), r2a = u31_to_unit(rnd[1]), r1b = u31_to_unit(rnd[2]), r2b = u31_to_unit(rnd[3]);
-		const f3 d0 = gi_direction(r1a, r2a, Nn, nt, nb), d1 = gi_direction(r1b, r2b, Nn, nt, nb);
+		const DirPair dp = gi_direction_pair(r1a, r2a, r1b, r2b, Nn, nt, nb);
+		const f3 d0 = dp.d0, d1 = dp.d1;
 		cn.rays += second ? 2u : 1u;
 		const RayPair rp = make_pair(d0, d1);
 		BestState s0, s1;

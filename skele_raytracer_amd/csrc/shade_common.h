@@ -273,7 +273,7 @@ SKR_DEV LightTerm light_term(const SceneView &sv, int i, f3 P)
 	}
 	const f3 to_l = ld3(lp4) - P;
 	t.len = sk_sqrtf(sqr3(to_l));
-	t.L = to_l * sk_divf(1.0f, t.len);
+	t.L = to_l * sk_rcpf(t.len);
 	return t;
 }
 
@@ -304,7 +304,7 @@ SKR_DEV f3 direct_light_of(const SceneView &sv, const RenderParams &p, f3 kd, f3
 			const bool lit = k ? (second && !occ1) : !occ0;
 			if(lit)
 			{
-				const float intensity = sk_divf(1.0f, t.len * t.len); // 1/powf(|d|,2) == 1/(d*d)
+				const float intensity = sk_rcpf(t.len * t.len); // 1/powf(|d|,2) == 1/(d*d)
 				diffuse = diffuse + ((kd * t.lc) * intensity) * max0(dot3(N, t.L));
 				const f3 vl = view + t.L;
 				const f3 H = vl / length3(vl);
@@ -325,18 +325,36 @@ SKR_DEV f3 direct_light(const SceneView &sv, const RenderParams &p, int sph, f3 
 }
 
 // raytrace.h:22-30 + :117-125: hemisphere sample and the reference's basis mix
-// (perp_to_both.y/.z where perp_to_normal.y/.z belongs — kept).
-// (out of line together with the binary64 sincos it calls: see device_math.h)
-static __device__ __attribute__((noinline)) f3 gi_direction(float r1, float r2, f3 N, f3 nt, f3 nb)
+// (perp_to_both.y/.z where perp_to_normal.y/.z belongs — kept), for the two sibling rays of a pair at once in packed binary32
+// (every component is the one-ray expression: v_pk_* round each half like the scalar instruction).
+#ifndef SKR_GI_INLINE
+#define SKR_GI_INLINE 0 // 1: inline gi_direction_pair into its callers (A/B builds)
+#endif
+struct DirPair { f3 d0, d1; }; // (returned by value: in registers, where reference parameters of an out-of-line function go through scratch)
+#if SKR_GI_INLINE
+SKR_DEV
+#else
+static __device__ __attribute__((noinline))
+#endif
+DirPair gi_direction_pair(float r1a, float r2a, float r1b, float r2b, f3 N, f3 nt, f3 nb)
 {
-	const float s_theta = sk_sqrtf(1 - r1 * r1);
-	const float phi = (float) ((2.0 * 3.14159265358979323846) * (double) r2); // (2.0f*M_PI)*r2 in double, narrowed
-	float sn, cs;
-	sincos_spec(phi, sn, cs);
-	const float sx = s_theta * cs, sy = r1, sz = s_theta * sn;
-	return mk3((sx * nb.x + sy * N.x) + sz * nt.x,
-			   (sx * nb.y + sy * N.y) + sz * nb.y,
-			   (sx * nb.z + sy * N.z) + sz * nb.z);
+	const f2 r1 = f2{r1a, r1b};
+	const f2 om = 1.0f - r1 * r1;
+	const f2 s_theta = f2{sk_sqrtf(om.x), sk_sqrtf(om.y)};
+	// (2.0f*M_PI)*r2 in double, narrowed (raytrace.h:25: `float phi = 2 * M_PI * r2`)
+	const f2 phi = f2{(float) ((2.0 * 3.14159265358979323846) * (double) r2a), (float) ((2.0 * 3.14159265358979323846) * (double) r2b)};
+	f2 sn, cs;
+	sincos_spec2(phi, sn, cs);
+	const f2 sx = s_theta * cs, sy = r1, sz = s_theta * sn;
+	const f2 x = (sx * nb.x + sy * N.x) + sz * nt.x;
+	const f2 y = (sx * nb.y + sy * N.y) + sz * nb.y;
+	const f2 z = (sx * nb.z + sy * N.z) + sz * nb.z;
+	return DirPair{mk3(x.x, y.x, z.x), mk3(x.y, y.y, z.y)};
+}
+
+SKR_DEV f3 gi_direction(float r1, float r2, f3 N, f3 nt, f3 nb)
+{
+	return gi_direction_pair(r1, r2, r1, r2, N, nt, nb).d0;
 }
 
 SKR_DEV uint32_t wave_sum(uint32_t v)

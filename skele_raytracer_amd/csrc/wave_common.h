@@ -128,7 +128,7 @@ SKR_DEV void primary_ray(const RenderParams &p, int x, uint32_t y, uint32_t pixe
 	if(p.grid_size > 0)
 	{
 		uint32_t rnd[4];
-		philox4x32_10(pixel, aa, 0u, 0xFFFFFFFFu, p.seed_lo, p.seed_hi, rnd);
+		philox4x32(pixel, aa, 0u, 0xFFFFFFFFu, p.seed_lo, p.seed_hi, rnd);
 		const float r = u31_to_unit(rnd[0]);
 		u = ((2 * (((float) x + r) * p.inv_width) - 1) * p.angle) * p.aspect;
 		v = (1 - 2 * (((float) (int) y + r) * p.inv_height)) * p.angle;

@@ -21,17 +21,23 @@ def test_philox(oracle):
     inp[0] = 0
     inp[1] = 0xFFFFFFFF
     inp[2] = [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0]
-    out = binding.debug_eval(0, inp, 4)
-    # Random123 known-answer vectors
-    assert out[0].tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
-    assert out[1].tolist() == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
-    assert out[2].tolist() == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    out = binding.debug_eval(0, inp, 4)   # the product's counter RNG: Philox4x32-7
+    out10 = binding.debug_eval(8, inp, 4)  # the same round function at Random123's default of 10 rounds
+    # Random123 known-answer vectors (kat_vectors: philox4x32 7 / philox4x32 10)
+    assert out[0].tolist() == [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]
+    assert out[1].tolist() == [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]
+    assert out[2].tolist() == [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]
+    assert out10[0].tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert out10[1].tolist() == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert out10[2].tolist() == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
     o = (C.c_uint32 * 4)()
     for i in range(0, 4096, 37):
         c = (C.c_uint32 * 4)(*inp[i, :4].tolist())
         k = (C.c_uint32 * 2)(*inp[i, 4:].tolist())
-        L.sko_philox4x32_10(c, k, o)
+        L.sko_philox4x32_spec(c, k, o)
         assert list(o) == out[i].tolist()
+        L.sko_philox4x32_10(c, k, o)
+        assert list(o) == out10[i].tolist()
 
 
 def test_sincos(oracle):
@@ -119,3 +125,12 @@ def test_float_sqrt_and_divide_are_correctly_rounded():
         want_d = (a.astype(np.float64) / b.astype(np.float64)).astype(np.float32)  # double quotient of floats rounds correctly (53 >= 2*24+2)
     assert np.array_equal(out[:, 0], want_s.view(np.uint32))
     assert np.array_equal(out[:, 1], want_d.view(np.uint32))
+
+
+def test_short_exact_forms_equal_the_correctly_rounded_ones_on_every_float():
+    """device_math.h sk_sqrtf / sk_rcpf (one Newton step on v_rsq / v_rcp for operands in [2^-100, 2^101), the compiler's expansion
+    elsewhere) and div_const (x / pi, x / pdf as fma(x, zh, x * zl) for x == 0 or |x| >= 2^-100): every one of the 2^32 binary32
+    operands, compared on the device with the expansions that test_float_sqrt_and_divide_are_correctly_rounded pins to IEEE."""
+    hi = np.arange(65536, dtype=np.uint32).reshape(-1, 1)
+    out = binding.debug_eval(9, hi, 4)
+    assert out.sum(axis=0).tolist() == [0, 0, 0, 0], out.sum(axis=0)
