@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py — the reference's headline benchmark on MI355X.
+"""bench.py — the reference's headline benchmark on MI355X, and the other BASELINE.json configurations measured the same way.
 
-Metric (BASELINE.json): Mrays/sec + frame ms, scenes/spheres2.scn 1920x1080 --gillum 16
---shadow (depth 3), on 1/2/4/8 MI355X.  A "step" is one whole frame: every rank renders its
-interleaved row tiles (C ABI, include/skr.h), the u8 tiles are gathered with ONE RCCL
-all-gather over xGMI and rank 0 de-interleaves them on the device — the whole step runs
-inside libskr (skr_comm_render_frame); torch.distributed only carries the 128-byte RCCL id
-and the barriers.  Inputs (the SoA scene) are resident in HBM before the timed region.
-`value` = radiance rays actually traced per second, whole job (rays = shade() calls with
-depth > 0, counted by the kernels themselves; deterministic and partition-independent).
-SURVEY.md §8d's closed form W*H*S*sum N^k is the full-tree upper bound (every ray hitting a
-sphere) and is reported beside it as `nominal_rays`.
+Metric (BASELINE.json): Mrays/sec + frame ms, scenes/spheres2.scn 1920x1080 --gillum 16 --shadow (depth 3), on 1/2/4/8
+MI355X.  A "step" is one whole frame: every rank renders its interleaved row tiles (C ABI, include/skr.h), the u8 tiles are
+gathered with ONE RCCL all-gather over xGMI and rank 0 de-interleaves them on the device — the whole step runs inside libskr
+(skr_comm_render_frame); torch.distributed only carries the 128-byte RCCL id and the barriers.  Inputs (the SoA scene) are
+resident in HBM before the timed region.  `value` = radiance rays actually traced per second, whole job (rays = shade() calls
+with depth > 0, counted by the kernels themselves; deterministic and partition-independent).  SURVEY.md 8d's closed form
+W*H*S*sum N^k is the full-tree upper bound and is reported beside it as `nominal_rays`.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--config 2|3|4|5] [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.
+--config picks the workload (BASELINE.json `configs`, 1-based as SURVEY.md 8d numbers them; default 3 = the headline):
+  2  spheres2.scn 1920x1080 --jsample 5 --shadow            3  spheres2.scn 1920x1080 --gillum 16 --shadow
+  4  dragon.scn   1920x1080 --gillum 16 (10 002 triangles)  5  spheres2.scn 3840x2160 --gillum 64 --jsample 5 --shadow
+
+Prints ONE JSON line on rank 0.  `roofline` is the bound that binds (FP32 VALU issue) for the dominant kernel: its own counted
+work over its own mean launch duration (HIP events on its stream); `roofline_hbm` is the figure north_star asks for (algorithmic
+bytes over the frame time, with the PMC-measured traffic beside it); `cpu_baseline` is the oracle on this box's host cores on a
+stated sample of the same workload.  A fallback from the frame step that was asked for is an error, not a note.
 """
 import argparse
 import hashlib
@@ -27,19 +31,35 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SCENE = os.path.join(ROOT, "tests", "golden", "scenes", "spheres2.scn")
-W, H = 1920, 1080
-KW = dict(gillum=16, shadow=True, depth=3, seed=20261004)
+SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
+SEED = 20261004
+# cpu_bands: the rows the CPU baseline renders — None = whole frames; (period, rows) = rows y with y % period < rows (spread over the
+# frame, whose cost is very non-uniform vertically), the rate scaled from the rays those rows trace (BASELINE.md 3 allows a subset)
+CONFIGS = {
+    2: dict(scene="spheres2.scn", w=1920, h=1080, kw=dict(jsample=5, shadow=True, depth=3), steps=300, warmup=20, cpu_bands=None,
+            workload="scenes/spheres2.scn 1920x1080 --jsample 5 --shadow (BASELINE.json configs[1])"),
+    3: dict(scene="spheres2.scn", w=1920, h=1080, kw=dict(gillum=16, shadow=True, depth=3), steps=600, warmup=30, cpu_bands=None,
+            workload="scenes/spheres2.scn 1920x1080 --gillum 16 --shadow --depth 3 (BASELINE.json configs[2])"),
+    4: dict(scene="dragon.scn", w=1920, h=1080, kw=dict(gillum=16, depth=3), steps=300, warmup=20, cpu_bands=(120, 4),
+            workload="scenes/dragon.scn 1920x1080 --gillum 16 (BASELINE.json configs[3]; 10 002 triangles, no spheres: shade() never recurses)"),
+    5: dict(scene="spheres2.scn", w=3840, h=2160, kw=dict(gillum=64, jsample=5, shadow=True, depth=3), steps=2, warmup=1, cpu_bands=(540, 1),
+            workload="scenes/spheres2.scn 3840x2160 --gillum 64 --jsample 5 --shadow (BASELINE.json configs[4]; the whole frame on however many GPUs --gpus names)"),
+}
 TILE_ROWS = 8  # interleaved row tiles (cost is very non-uniform vertically: sky rows vs ground rows)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
-FLOP_PER_SPHERE_TEST, FLOP_PER_SHADED_HIT = 34, 150
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+# flops per ray-sphere test, per ray-triangle test (precomputed edges: 46), per shaded hit; a culling-sphere test of the
+# triangle walk (shade_common.h line_touches: cross, dot, one product, one compare) is 19
+FLOP_SPHERE_TEST, FLOP_TRI_TEST, FLOP_TRI_TEST_REF, FLOP_CULL_TEST, FLOP_SHADED_HIT = 34, 46, 58, 19, 150
 # the files whose contents decide what the kernels move: the measured traffic is only reported for the exact sources it was measured on
 KERNEL_SOURCES = ["skele_raytracer_amd/csrc/render_nodes.hip", "skele_raytracer_amd/csrc/render_wave.hip", "skele_raytracer_amd/csrc/wave_common.h",
                   "skele_raytracer_amd/csrc/shade_common.h", "skele_raytracer_amd/csrc/device_math.h", "skele_raytracer_amd/csrc/render_params.h"]
-DOMINANT = {"node_levels_v5": "skr_leaf_kernel2<false, false>", "node_levels_v5_flat": "skr_trace_kernel<false> (last level) + skr_shade_leaf_kernel<false>", "level_queues_v4": "skr_leaf_kernel<false>", "parent_queue_v3": "skr_gi_kernel<3, 3, false>",
-            "wave_streaming_v2": "skr_wave_kernel<3, 3>"}
+DOMINANT = {"node_levels_v5": "skr_leaf_kernel2<false, false>", "node_levels_v5_flat": "skr_trace_kernel<false> (last level) + skr_shade_leaf_kernel<false>",
+            "wave_streaming_v2": "skr_wave_kernel<1, 3>"}
+
+
+def traffic_json(config):
+    return os.path.join(ROOT, "profiles", "r03_hbm_traffic.json" if config == 3 else "r03_hbm_traffic_config%d.json" % config)
 
 
 def git_blob_hash(path):
@@ -53,14 +73,15 @@ def source_hashes():
     return {p: git_blob_hash(os.path.join(ROOT, p)) for p in KERNEL_SOURCES}
 
 
-def measured_traffic(variant):
+def measured_traffic(config, variant):
     """HBM bytes per frame over ALL kernels of the frame from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
-    this command (tools/pmc_traffic.sh; FETCH doubled per MI355X_MICROARCH.md) — or None when the kernel sources have changed since."""
+    this command (tools/pmc_traffic.py; FETCH doubled per MI355X_MICROARCH.md) — or None when the kernel sources have changed since."""
+    path = traffic_json(config)
     try:
-        with open(TRAFFIC_JSON) as f:
+        with open(path) as f:
             tj = json.load(f)
     except (OSError, ValueError):
-        return None, "no %s" % os.path.relpath(TRAFFIC_JSON, ROOT)
+        return None, "no %s" % os.path.relpath(path, ROOT)
     if tj.get("variant") != variant:
         return None, "measured for kernel variant %s" % tj.get("variant")
     if tj.get("sources") != source_hashes():
@@ -68,44 +89,59 @@ def measured_traffic(variant):
     return tj, None
 
 
-def reference_sample(orc):
-    """The reference's own shade()/parseScene() (oracle/_ref/ref_render: its sources compiled in place in the build
-    container, serial entry — the only one that can run this configuration) on ONE core, on a 320x180 sample of the
-    headline configuration; the ray count comes from the oracle's replay mode, which is bit-identical to it."""
+def reference_sample(orc, cfg):
+    """The reference's own shade()/parseScene() (oracle/_ref/ref_render: its sources compiled in place in the build container,
+    serial entry — the only one that honours these options) on ONE core, on a small frame of the same configuration; the ray
+    count comes from the oracle's replay mode, which is bit-identical to it."""
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_render")
     if not os.path.exists(exe):
         return None
     import subprocess
     import tempfile
-    w, h = 320, 180
+    kw = cfg["kw"]
+    w, h = (320, 180) if "gillum" in kw and cfg["scene"] != "dragon.scn" and not kw.get("jsample") else (160, 90)
+    if kw.get("gillum", 0) >= 64:
+        w, h = 64, 36
+    scene = os.path.join(SCENES, cfg["scene"])
+    args = ["--path", scene, "--width", str(w), "--height", str(h), "--depth", str(kw["depth"]), "--seed", "1"]
+    if "gillum" in kw:
+        args += ["--gillum", str(kw["gillum"])]
+    if kw.get("jsample"):
+        args += ["--jsample", str(kw["jsample"])]
+    if kw.get("shadow"):
+        args += ["--shadow"]
     try:
         with tempfile.TemporaryDirectory() as tmp:
             t0 = time.perf_counter()
-            subprocess.run([exe, "--path", SCENE, "--output", os.path.join(tmp, "ref.ppm"), "--width", str(w), "--height", str(h), "--gillum", str(KW["gillum"]),
-                            "--shadow", "--depth", str(KW["depth"]), "--seed", "1"], check=True, capture_output=True, timeout=120, cwd=tmp)
+            subprocess.run([exe] + args + ["--output", os.path.join(tmp, "ref.ppm")], check=True, capture_output=True, timeout=300, cwd=tmp)
             dt = time.perf_counter() - t0
-        _, _, st = orc.render(SCENE, w, h, rng=orc.RNG_GLIBC_REPLAY, math=orc.MATH_LIBM, gillum=KW["gillum"], shadow=KW["shadow"], depth=KW["depth"], seed=1)
+        _, _, st = orc.render(scene, w, h, rng=orc.RNG_GLIBC_REPLAY, math=orc.MATH_LIBM, seed=1, **kw)
         return {"value": int(st[0]) / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
-                "sample": "oracle/_ref/ref_render %dx%d --gillum %d --shadow: %d radiance rays in %.2f s (process start and scene parse included)" % (w, h, KW["gillum"], int(st[0]), dt)}
+                "sample": "oracle/_ref/ref_render %dx%d %s: %d radiance rays in %.2f s (process start and scene parse included)" % (w, h, " ".join(args[6:-2]), int(st[0]), dt)}
     except Exception as e:  # the checker binary is optional; the port above is the baseline
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
 
-def cpu_baseline():
-    """The oracle (CPU restatement, counter RNG, OpenMP over (row, 32-pixel span) items) timed on this
-    box's host cores on the same workload: whole frames, repeated until >= 8 s of wall time."""
+def cpu_baseline(cfg):
+    """The oracle (CPU restatement, counter RNG, OpenMP over (row, 32-pixel span) items) timed on this box's host cores on the
+    same workload: whole frames, or the stated rows of it, repeated until >= 8 s of wall time."""
     from oracle import pyoracle as orc
     cores = orc.host_cores()
-    scene = orc.OracleScene(SCENE)
-    kw = dict(rng=orc.RNG_COUNTER, math=orc.MATH_SHARED, threads=cores, gillum=KW["gillum"], shadow=KW["shadow"],
-              depth=KW["depth"], seed=KW["seed"])
-    orc.render(scene, W, H, y0=0, y1=64, **kw)  # warm up the thread pool
-    rays, frames = 0, 0
+    scene = orc.OracleScene(os.path.join(SCENES, cfg["scene"]))
+    W, H = cfg["w"], cfg["h"]
+    kw = dict(rng=orc.RNG_COUNTER, math=orc.MATH_SHARED, threads=cores, seed=SEED, **cfg["kw"])
+    bands = [(0, H)]
+    if cfg["cpu_bands"]:
+        period, rows = cfg["cpu_bands"]
+        bands = [(y, min(H, y + rows)) for y in range(period // 2, H, period)]
+    orc.render(scene, W, H, y0=bands[0][0], y1=bands[0][1], **kw)  # warm up the thread pool
+    rays, passes = 0, 0
     t0 = time.perf_counter()
-    while frames < 2 or time.perf_counter() - t0 < 8.0:
-        _, _, st = orc.render(scene, W, H, **kw)
-        rays += int(st[0])
-        frames += 1
+    while passes < (1 if cfg["cpu_bands"] else 2) or time.perf_counter() - t0 < 8.0:
+        for y0, y1 in bands:
+            _, _, st = orc.render(scene, W, H, y0=y0, y1=y1, **kw)
+            rays += int(st[0])
+        passes += 1
     dt = time.perf_counter() - t0
     model = "unknown"
     try:
@@ -114,24 +150,34 @@ def cpu_baseline():
     except OSError:
         pass
     host = os.cpu_count() or cores
-    reference = reference_sample(orc)
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "host_cores": host, "kind": "port", "cpu_model": model, "reference_1core": reference,
-            "ms_per_frame": dt / frames * 1e3,
-            "sample": "oracle/liboracle.so (C restatement of the reference path, gcc -O2, OpenMP) on %d of this host's %d cores — the box's cgroup CPU quota; "
-                      "scaled to all %d cores the baseline would be ~%.0fx higher — %d whole frames of the same workload: %d radiance rays in %.2f s"
-                      % (cores, host, host, host / max(1, cores), frames, rays, dt)}
+    n_rows = sum(b - a for a, b in bands)
+    what = ("%d whole frames" % passes) if not cfg["cpu_bands"] else ("%d passes over %d of the frame's %d rows (rows y with y %% %d in [%d, %d): spread over the frame; the rate is rays of those rows over their time)"
+                                                                    % (passes, n_rows, H, cfg["cpu_bands"][0], cfg["cpu_bands"][0] // 2, cfg["cpu_bands"][0] // 2 + cfg["cpu_bands"][1]))
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "host_cores": host, "kind": "port", "cpu_model": model, "reference_1core": reference_sample(orc, cfg),
+            "ms_per_frame": (dt / passes * 1e3) if not cfg["cpu_bands"] else (dt / passes * 1e3 * H / n_rows),
+            "sample": "oracle/liboracle.so (C restatement of the reference path, gcc -O2, OpenMP) on %d of this host's %d hardware threads — the box's cgroup CPU quota; "
+                      "scaled to all %d the baseline would be ~%.0fx higher — %s of the same workload: %d radiance rays in %.2f s"
+                      % (cores, host, host, host / max(1, cores), what, rays, dt)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=600)   # >= 1 s of frames at one GPU: the clock the chip settles at, not its first milliseconds
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json configuration (default 3: the headline)")
+    ap.add_argument("--steps", type=int, default=None)   # default per configuration: >= 1 s of frames at one GPU for the headline (the clock the chip settles at, not its first milliseconds)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--async-frames", action="store_true", help="the pipelined frame step at N = 1 too (it is the default for N > 1)")
     ap.add_argument("--sync-frames", action="store_true", help="libskr's frame step with the collective on the render stream (skr_comm_render_frame) instead of pipelined behind the next frame")
     ap.add_argument("--torch-gather", action="store_true", help="the round-1 frame step (torch.distributed all_gather + torch de-interleave) instead of libskr's")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.steps is None:
+        args.steps = cfg["steps"]
+    if args.warmup is None:
+        args.warmup = cfg["warmup"]
+    W, H, KW = cfg["w"], cfg["h"], dict(cfg["kw"], seed=SEED)
+    SCENE = os.path.join(SCENES, cfg["scene"])
 
     import numpy as np
     import torch
@@ -163,15 +209,27 @@ def main():
 
     from skele_raytracer_amd.distributed import FrameSharder
 
+    def fail(msg):
+        """A frame step other than the one asked for is not a measurement of it: every rank leaves, non-zero."""
+        sys.stderr.write("bench.py: %s\n" % msg)
+        sys.stderr.flush()
+        if world > 1:
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+        sys.exit(3)
+
     scene = skr.parse_scene(SCENE)
     r = skr.Renderer(scene, local_rank)
     opt = skr.Options(W, H, **KW)
     stream = torch.cuda.current_stream(dev)
     k_max = binding.shard_tiles_per_rank(H, TILE_ROWS, world)
 
-    # the frame step: libskr's own (RCCL inside the library) unless it cannot be set up — then, and on request, round 1's
-    comm, native_note = None, None
+    # the frame step: libskr's own (RCCL inside the library); --torch-gather (and the one-GPU rehearsal, which has no RCCL peers) asks for round 1's
+    comm = None
     if not args.torch_gather and not rehearsal:
+        err = None
         try:
             uid = None
             if world > 1:
@@ -182,12 +240,14 @@ def main():
                 uid = bytes(t.cpu().numpy().tobytes())
             comm = binding.Comm(r, rank, world, uid)
         except skr.SkrError as e:
-            native_note = "libskr's RCCL step unavailable (%s): torch.distributed all_gather used" % str(e)[:160]
-    if world > 1:  # every rank takes the same path
-        ok = torch.tensor([1 if comm is not None else 0], device=dev) if not rehearsal else torch.tensor([0])
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            comm = None
+            err = str(e)[:200]
+        ok = 1 if comm is not None else 0
+        if world > 1:
+            t_ok = torch.tensor([ok], device=dev)
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            ok = int(t_ok.item())
+        if not ok:
+            fail("libskr's RCCL frame step could not be set up on every rank (%s); run with --torch-gather to measure the torch.distributed step instead" % (err or "another rank failed"))
     sharder = None if comm is not None else FrameSharder(W, H, TILE_ROWS, rank, world, dev)
 
     # (at N = 1 there is no collective to hide and the two extra stream waits cost 1 %: measured 1.796 against 1.779 ms)
@@ -202,19 +262,20 @@ def main():
             sharder.step(lambda buf: r.render_tiles_into(opt, TILE_ROWS, rank, world, buf.data_ptr(), None, stream.cuda_stream))
 
     if pipelined:
-        # one pipelined frame before anything is timed: a rank on which it cannot be set up takes every rank back to the serial step
-        ok_async = 1
+        # one pipelined frame before anything is timed: it either works on every rank or the run is not the one that was asked for
+        ok_async, err = 1, None
         try:
             comm.render_frame_async(opt, TILE_ROWS, stream.cuda_stream, want_previous=False)
             comm.flush(stream.cuda_stream)
             torch.cuda.synchronize(dev)
         except skr.SkrError as e:
-            ok_async, native_note = 0, "pipelined frame step unavailable (%s): serial skr_comm_render_frame used" % str(e)[:160]
+            ok_async, err = 0, str(e)[:200]
         if world > 1:
             t_ok = torch.tensor([ok_async], device=dev)
             dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
             ok_async = int(t_ok.item())
-        pipelined = bool(ok_async)
+        if not ok_async:
+            fail("the pipelined frame step (skr_comm_render_frame_async) failed (%s); run with --sync-frames to measure the serial step instead" % (err or "on another rank"))
 
     def sync():
         if pipelined:
@@ -226,6 +287,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    r.triangle_work(reset=True)
     r.work(reset=True)
     sync()
     t0 = time.perf_counter()
@@ -237,26 +299,32 @@ def main():
     variant = r.kernel_variant()
     queued = r.last_parent_count()
     level1 = r.last_level1_count()
+    tri = r.triangle_work(reset=True)   # (before the counters it scales are reset)
     cnt = r.work(reset=True)
-    # the dominant kernel alone: HIP events on its stream around every launch of a short extra pass (not in the timed region)
+    # the dominant kernel alone: HIP events on its stream around every launch of a short extra pass (not in the timed region),
+    # and the work counters copied in front of and behind it (skr_renderer_kernel_work)
     r.kernel_timing(True)
     r.kernel_ms()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n_probe = min(args.steps, 50)
-    r.render_tiles_into(opt, TILE_ROWS, rank, world, r_probe_buf(torch, dev, k_max).data_ptr(), None, stream.cuda_stream)  # (allocates the probe buffer)
+    probe = torch.zeros((k_max * TILE_ROWS, W, 3), dtype=torch.uint8, device=dev)
+    r.render_tiles_into(opt, TILE_ROWS, rank, world, probe.data_ptr(), None, stream.cuda_stream)
     torch.cuda.synchronize(dev)
     r.kernel_ms()
     e0.record(stream)
     for _ in range(n_probe):
-        r.render_tiles_into(opt, TILE_ROWS, rank, world, r_probe_buf(torch, dev, k_max).data_ptr(), None, stream.cuda_stream)
+        r.render_tiles_into(opt, TILE_ROWS, rank, world, probe.data_ptr(), None, stream.cuda_stream)
     e1.record(stream)
     torch.cuda.synchronize(dev)
     kernel_ms, _ = r.kernel_ms()
+    kwork = r.kernel_work()
     r.kernel_timing(False)
     pipeline_ms = e0.elapsed_time(e1) / n_probe  # everything this rank enqueues per frame before the collective
+    r.triangle_work(reset=True)
     r.work(reset=True)
 
-    stats = torch.tensor([dt, float(cnt["radiance_rays"]), float(cnt["shadow_rays"]), float(cnt["sphere_hits"]), float(cnt["sphere_tests"]), kernel_ms, pipeline_ms],
+    stats = torch.tensor([dt, float(cnt["radiance_rays"]), float(cnt["shadow_rays"]), float(cnt["sphere_hits"]), float(cnt["sphere_tests"]), kernel_ms, pipeline_ms,
+                          float(tri["cull_tests"]), float(tri["triangle_tests"]), float(tri["reference_triangle_tests"])],
                          dtype=torch.float64, device=dev if not rehearsal else "cpu")
     if world > 1:
         mx = stats.clone()
@@ -264,81 +332,93 @@ def main():
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt, kernel_ms, pipeline_ms = float(mx[0]), float(mx[5]), float(mx[6])
-        rays, shadow, hits, tests = float(sm[1]), float(sm[2]), float(sm[3]), float(sm[4])
+        tot = sm
     else:
-        rays, shadow, hits, tests = float(stats[1]), float(stats[2]), float(stats[3]), float(stats[4])
+        tot = stats
+    rays, shadow, hits, tests = float(tot[1]), float(tot[2]), float(tot[3]), float(tot[4])
+    cull_tests, tri_tests, tri_tests_ref = float(tot[7]), float(tot[8]), float(tot[9])
 
     if rank == 0:
         n = args.steps
         rays_per_frame = rays / n
         ms_per_step = dt / n * 1e3
         info = scene.info
-        # ---- HBM roofline, as SURVEY.md §8(d) defines it: the algorithm's compulsory bytes per frame — the u8 framebuffer out and one read of
-        # the scene — over the frame time.  (0.011 B per nominal ray x the rays of a frame.)  Structurally ~4e-4 of peak: this path is not
-        # HBM-bound; what the pipeline itself moves between its kernels is `pipeline_bytes`, what the counters saw is `traffic`.
+        nsamp = max(1, KW.get("jsample", 0) ** 2)
+        # ---- HBM, as SURVEY.md 8(d) defines it: the algorithm's compulsory bytes per frame — the u8 framebuffer out and one read of the scene —
+        # over the frame time.  Structurally ~4e-4 of peak: this path is not HBM-bound; what the counters saw is `traffic`.
         scene_bytes = info.n_spheres * 64 + info.n_point_lights * 32 + info.n_triangles * 48
         alg_bytes = W * H * 3 + scene_bytes
         achieved_gbs = alg_bytes / (ms_per_step * 1e-3) / 1e9
         # the node pipeline's own tables (one band = the frame): a level-0 node is a 32-byte geometry row (read by the trace kernel and, gathered,
         # by the leaf kernel) and a 32-byte shading row (read by finalize); a level-1 record is 16 bytes written and read, its result 12 bytes
         # written and read; every trace wave (64 sibling pairs) leaves a 48-byte header that finalize reads
-        N = KW["gillum"]
-        pipeline_bytes = (queued * (64 + 3 * 32) + level1 * (2 * 16 + 2 * 12) + (queued * ((N + 1) // 2) + 63) // 64 * 48 * 2) if variant == "node_levels_v5" else None
-        tj, why = measured_traffic(variant) if world == 1 else (None, "measured at N = 1 only")
+        N = KW.get("gillum", 0)
+        pipeline_bytes = (queued * (64 + 3 * 32) + level1 * (2 * 16 + 2 * 12) + (queued * ((N + 1) // 2) + 63) // 64 * 48 * 2) if variant == "node_levels_v5" and nsamp == 1 else None
+        tj, why = measured_traffic(args.config, variant) if world == 1 else (None, "measured at N = 1 only")
         traffic = tj["traffic_bytes_per_frame"] if tj else None
-        # ---- FP32-VALU roofline: the flops the reference's algorithm needs for this frame — every ray-sphere test it would run (early-outs of the
-        # shadow walks counted by the kernels, asserted equal to the oracle's count) and every shaded hit — over the frame time, per GPU
-        alg_flop = tests / n * FLOP_PER_SPHERE_TEST + hits / n * FLOP_PER_SHADED_HIT
-        valu_tflops = alg_flop / (ms_per_step * 1e-3) / 1e12 / world
+        # ---- FP32 VALU.  Executed work: every ray-sphere test the reference runs (a shadow walk stops at its first occluder: counted by the
+        # kernels, asserted equal to the oracle's count), every shaded hit, and for meshes the tests the culled walk EXECUTED (counted by the
+        # walk: lanes that needed the test) — not the 10 002 per ray of the reference's loop, which the exact culling provably never needs.
+        frame_flop = (tests * FLOP_SPHERE_TEST + hits * FLOP_SHADED_HIT + tri_tests * FLOP_TRI_TEST + cull_tests * FLOP_CULL_TEST) / n
+        frame_flop_ref = (tests * FLOP_SPHERE_TEST + hits * FLOP_SHADED_HIT + tri_tests_ref * FLOP_TRI_TEST_REF) / n
+        frame_tflops = frame_flop / (ms_per_step * 1e-3) / 1e12 / world
+        # the dominant kernel's own share (skr_renderer_kernel_work: counters copied around it; mesh walks are not split per kernel: whole-frame
+        # figure where the wave kernel IS the frame).  The wave kernel traces all the AA samples of a frame in one launch.
+        whole_frame_kernel = variant == "wave_streaming_v2"
+        if whole_frame_kernel:
+            kernel_flop = frame_flop
+        else:
+            kernel_flop = kwork["sphere_tests"] * FLOP_SPHERE_TEST + kwork["sphere_hits"] * FLOP_SHADED_HIT
+        kernel_tflops = (kernel_flop / (kernel_ms * 1e-3) / 1e12) if kernel_ms > 0 else 0.0
         out = {
-            "metric": "Mrays/sec + frame ms, 1920x1080 gillum=16 spheres2.scn",
+            "metric": "Mrays/sec + frame ms, 1920x1080 gillum=16 spheres2.scn" if args.config == 3 else "Mrays/sec + frame ms, BASELINE.json configs[%d]" % (args.config - 1),
             "value": rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": n, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "reference scene file scenes/spheres2.scn (spherical_fog line skipped: UB in the reference)",
-            "config": {"workload": "scenes/spheres2.scn 1920x1080 --gillum 16 --shadow --depth 3 (BASELINE.json configs[2])",
+            "dtype": "f32", "data": "reference scene file scenes/%s%s" % (cfg["scene"], " (spherical_fog line skipped: UB in the reference)" if cfg["scene"] == "spheres2.scn" else ""),
+            "config": {"workload": cfg["workload"], "baseline_config": args.config,
                        "rays_per_frame": rays_per_frame, "nominal_rays": skr.radiance_ray_count(opt),
                        "nominal_mrays_per_s": skr.radiance_ray_count(opt) * n / dt / 1e6,
                        "shadow_rays_per_frame": shadow / n, "sphere_tests_per_frame": tests / n, "shaded_hits_per_frame": hits / n,
+                       "triangle_tests_executed_per_frame": tri_tests / n, "culling_sphere_tests_executed_per_frame": cull_tests / n,
+                       "triangle_tests_of_the_reference_loop_per_frame": tri_tests_ref / n,
                        "partition": "interleaved %d-row tiles, rank = tile %% %d" % (TILE_ROWS, world),
                        "frame_step": ("REHEARSAL on one GPU over gloo - not a measurement" if rehearsal else
                                       (("libskr skr_comm_render_frame_async: tiles -> ncclAllGather (RCCL, in the library) -> de-interleave kernel on rank 0, the collective of frame f on its own stream behind the render of frame f + 1; the last frame's collective inside the timed region" if pipelined else "libskr skr_comm_render_frame: tiles -> ncclAllGather (RCCL, in the library) -> de-interleave kernel on rank 0") if comm is not None else
-                                       "torch.distributed all_gather_into_tensor of the u8 tile buffers, rank 0 de-interleaves (torch)")) if world > 1
-                                     else (("libskr skr_comm_render_frame_async (1 GPU: tiles, then the de-interleave kernel on the communicator's stream; no collective)" if pipelined else "libskr skr_comm_render_frame (1 GPU: tiles + de-interleave kernel, no collective)") if comm is not None else "skr_render_tiles"),
-                       "frame_step_note": native_note, "kernel": variant, "seed": KW["seed"]},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
-                         "traffic_per_kernel": tj.get("per_kernel") if tj else None,
-                         "traffic_source": ("profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over every kernel of the frame, FETCH doubled "
-                                            "per the gfx950 note; keyed by the git blob hashes of the kernel sources") if traffic else why,
-                         "algorithmic_bytes_per_frame": alg_bytes, "pipeline_bytes": pipeline_bytes,
-                         "kernel": DOMINANT.get(variant, "skr_render_kernel<3>"), "kernel_ms": kernel_ms, "render_ms": pipeline_ms,
-                         "level0_nodes": queued, "level1_records": level1,
-                         "note": "SURVEY.md 8(d): algorithmic bytes = W*H*3 + scene per frame, over ms_per_step; this path is bound by FP32 VALU issue, not by HBM (roofline_valu); "
-                                 "kernel_ms = the dominant kernel's mean launch duration (HIP events on its stream, a separate untimed pass)"},
-            "roofline_valu": {"bound": "fp32_valu", "achieved": valu_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu_tflops / VALU_PEAK_TFLOPS,
-                              "algorithmic_gflop_per_frame": alg_flop / 1e9,
-                              "note": "frame flops over frame time per GPU: %d flop per ray-sphere test the reference runs (shadow walks stop at their first occluder: counted, "
-                                      "not assumed), %d per shaded hit (SURVEY.md 8d); the spec forbids FMA contraction, so 1/2 of the FMA peak is the ceiling of this instruction stream"
-                                      % (FLOP_PER_SPHERE_TEST, FLOP_PER_SHADED_HIT)},
+                                       "torch.distributed all_gather_into_tensor of the u8 tile buffers, rank 0 de-interleaves (torch) [--torch-gather]")) if world > 1
+                                     else (("libskr skr_comm_render_frame_async (1 GPU: tiles, then the de-interleave kernel on the communicator's stream; no collective)" if pipelined else "libskr skr_comm_render_frame (1 GPU: tiles + de-interleave kernel, no collective)") if comm is not None else "skr_render_tiles + torch de-interleave [--torch-gather]"),
+                       "kernel": variant, "seed": KW["seed"]},
+            "roofline": {"bound": "fp32_valu", "achieved": kernel_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kernel_tflops / VALU_PEAK_TFLOPS,
+                         "traffic": traffic,
+                         "kernel": DOMINANT.get(variant, variant), "kernel_ms": kernel_ms, "kernel_gflop_per_launch": kernel_flop / 1e9,
+                         "kernel_work_per_launch": (dict(kwork) if not whole_frame_kernel else
+                                                    {"sphere_tests": tests / n, "sphere_hits": hits / n, "triangle_tests": tri_tests / n, "cull_tests": cull_tests / n}),
+                         "frame": {"achieved": frame_tflops, "frac": frame_tflops / VALU_PEAK_TFLOPS, "gflop_per_frame": frame_flop / 1e9,
+                                   "reference_loop_gflop_per_frame": frame_flop_ref / 1e9, "ms": ms_per_step},
+                         "note": "the bound that binds: FP32 VALU issue (branchy scalar FP32; no MFMA; HBM at 4e-4 of peak: roofline_hbm).  achieved = the dominant kernel's own counted work "
+                                 "(%d flop per ray-sphere test the reference runs — shadow walks stop at their first occluder: counted, not assumed — %d per shaded hit, %d per ray-triangle test and %d per "
+                                 "culling-sphere test the walk EXECUTED; SURVEY.md 8d) over its mean launch duration (HIP events on its stream, a separate untimed pass).  `frame` is the same over the whole "
+                                 "frame time; `reference_loop_gflop_per_frame` prices the triangle loop as the reference runs it (every triangle for every ray, %d flop each), which the exact culling never "
+                                 "executes.  The spec forbids FMA contraction, so half the FMA peak is the ceiling of this instruction stream."
+                                 % (FLOP_SPHERE_TEST, FLOP_SHADED_HIT, FLOP_TRI_TEST, FLOP_CULL_TEST, FLOP_TRI_TEST_REF)},
+            "roofline_hbm": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                             "traffic": traffic, "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                             "traffic_per_kernel": tj.get("per_kernel") if tj else None,
+                             "traffic_source": ("%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over every kernel of the frame, FETCH doubled per the gfx950 note; keyed by the "
+                                                "git blob hashes of the kernel sources" % os.path.relpath(traffic_json(args.config), ROOT)) if traffic else why,
+                             "algorithmic_bytes_per_frame": alg_bytes, "pipeline_bytes": pipeline_bytes, "render_ms": pipeline_ms,
+                             "level0_nodes": queued, "level1_records": level1,
+                             "note": "north_star's requested figure — SURVEY.md 8(d): algorithmic bytes = W*H*3 + scene per frame, over ms_per_step; this path is not HBM-bound"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(cfg)
             out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["config"]["gpu_over_cpu_note"] = "against %d of the host's %d hardware threads (the box's cgroup quota)" % (out["cpu_baseline"]["cores"], out["cpu_baseline"]["host_cores"])
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-_probe = {}
-
-
-def r_probe_buf(torch, dev, k_max):
-    if "b" not in _probe:
-        _probe["b"] = torch.zeros((k_max * TILE_ROWS, W, 3), dtype=torch.uint8, device=dev)
-    return _probe["b"]
 
 
 if __name__ == "__main__":

@@ -181,6 +181,15 @@ int skr_renderer_read_counters(skr_renderer *r, uint64_t out[3], int reset);
  * (raytrace.h:152-165), up to and including the first occluder for a shadow ray (utils.h:52-55).  The
  * numerator of bench.py's FP32-VALU roofline; asserted equal to the oracle's count. */
 int skr_renderer_read_work(skr_renderer *r, uint64_t out[4], int reset);
+/* The work (as skr_renderer_read_work counts it) of the ONE kernel skr_renderer_kernel_ms times, in the last launch made with kernel
+ * timing on: the counters are copied on the launch stream in front of and behind that kernel, outside the timed window.  Do not
+ * reset the counters between that launch and this call.  Synchronous. */
+int skr_renderer_kernel_work(skr_renderer *r, uint64_t out[4]);
+/* What the triangle walks did since the last reset (synchronous; read it BEFORE resetting the counters above): out[0] culling-sphere
+ * tests and out[1] ray-triangle tests (utils.h:181-213) the kernels executed — lanes that needed the test, counted by the walks
+ * themselves —, out[2] the ray-triangle tests the reference's loop runs for the same rays (raytrace.h:171-186: every triangle for
+ * every radiance ray).  bench.py prices mesh scenes with out[0] and out[1]; out[2] / out[1] is what the exact culling saves. */
+int skr_renderer_read_triangle_work(skr_renderer *r, uint64_t out[3], int reset);
 /* The SKR_* development switches (kernel variant, budgets: DESIGN.md) are read from the environment
  * once, at skr_renderer_create; this reads them again (tests and A/B tools change them between frames). */
 int skr_renderer_reload_switches(skr_renderer *r);

@@ -29,6 +29,16 @@
 //    draw order is the reference's DFS order.
 //  * --parallel-entry reproduces generate_rays_parallel's overrides
 //    (main.cpp:21-24: 640x480, depth 1, no jitter).
+//
+// --legacy / --eval-legacy (round 3).  direct_illumination() returns at raytrace.h:44; behind the return sits the
+// reflection / refraction / Fresnel code (:45-103), unreachable — so no run of the reference's shade() can exercise it.  What CAN
+// be run is every function that code calls: bp::fresnel (blinn_phong.h:156), bp::refraction (:143), bp::reflect_direction (:137)
+// are ordinary functions.  --eval-legacy dumps them on 10 000 inputs (the oracle's restatements must give the same bits:
+// FUNCTION-LEVEL pin).  --legacy renders with shade_legacy() below: the control flow of raytrace.h:139-227 and :36-103 with the
+// early return taken out, restated here, around the reference's own intersection_occurs / collision_distance /
+// triangle_intersection_occurs / smallest_root / bp::ambient, diffuse, specular / bp::fresnel, refraction, reflect_direction —
+// every number is computed by reference code, only the order of the calls is restated (COMPOSITION restated).  Without --gillum
+// (montecarlo_global_illumination calls the reference's own shade(), which would leave the mode).
 
 #include <cstdio>
 #include <cstdlib>
@@ -118,12 +128,113 @@ static void dump_scene(const char *path, const Scene &s)
 	fclose(f);
 }
 
+// raytrace.h:139-227 + :36-103 with the `return total_colour;` of :44 taken out (see the header): control flow restated,
+// every value from the reference's own functions.
+static glm::vec3 shade_legacy(Ray ray, const Scene &scene, int depth)
+{
+	if(depth <= 0) return glm::vec3(0.0f, 0.0f, 0.0f); // :141-144
+	float min_distance = INFINITY;
+	int sphere_index = -1;
+	bool hit_a_sphere = false, hit_a_triangle = false;
+	for(unsigned int i = 0; i < scene.spheres.size(); i++) // :152-165
+		if(intersection_occurs(ray, scene.spheres[i].collider))
+		{
+			hit_a_sphere = true;
+			float distance = collision_distance(ray, scene.spheres[i].collider);
+			if(distance < min_distance)
+			{
+				min_distance = distance;
+				sphere_index = (int) i;
+			}
+		}
+	for(unsigned int i = 0; i < scene.triangles.size(); i++) // :171-186
+	{
+		float t, u, v;
+		if(triangle_intersection_occurs(ray, scene.triangles[i], t, u, v) && t < min_distance)
+		{
+			min_distance = t;
+			hit_a_sphere = false;
+			hit_a_triangle = true;
+		}
+	}
+	if(!hit_a_sphere && !hit_a_triangle) return scene.background; // :189-192
+	if(!hit_a_sphere) return glm::vec3(0.0f, 0.0f, 0.0f);         // :221-224
+	const Sphere &sphere = scene.spheres[sphere_index];
+	// :197-205
+	glm::vec3 e_c = ray.position - sphere.collider.position;
+	float a = glm::dot(ray.direction, ray.direction);
+	float b = 2 * glm::dot(ray.direction, e_c);
+	float c = glm::dot(e_c, e_c) - sphere.collider.radius * sphere.collider.radius;
+	float t = smallest_root(a, b, c);
+	glm::vec3 P = ray.position + ray.direction * t;
+	glm::vec3 N = glm::normalize(P - sphere.collider.position);
+	// :38-42
+	glm::vec3 total_colour = glm::vec3(0.0f, 0.0f, 0.0f);
+	total_colour += bp::ambient_shading(scene, sphere);
+	total_colour += bp::diffuse_shading(scene, sphere, P, N);
+	total_colour += bp::specular_shading(scene, sphere, P, N);
+	// :45-102
+	float fr = bp::fresnel(ray.direction, N, sphere);
+	glm::vec3 refraction_colour = glm::vec3(0.0f, 0.0f, 0.0f), reflection_colour = glm::vec3(0.0f, 0.0f, 0.0f);
+	if(sphere.material.specular != glm::vec3(0.0f, 0.0f, 0.0f) && depth > 0)
+	{
+		const size_t n_point = scene.point_lights.size(), n_all = n_point + scene.directional_lights.size();
+		for(size_t i = 0; i < n_all; i++)
+		{ // :54-77 for the point lights, then :80-99 for the directional ones: the same statements around another light direction
+			glm::vec3 light_direction = i < n_point ? glm::normalize(scene.point_lights[i].position - P) : glm::normalize(scene.directional_lights[i - n_point].direction);
+			if(fr < 1)
+			{
+				Ray refracted_ray;
+				refracted_ray.position = P;
+				refracted_ray.direction = bp::refraction(ray.direction, N, sphere);
+				refraction_colour = fr * shade_legacy(refracted_ray, scene, depth - 1); // (an assignment at :70 / :92: the last light's stays)
+			}
+			Ray reflected_ray;
+			reflected_ray.position = P;
+			reflected_ray.direction = bp::reflect_direction(light_direction, N);
+			reflection_colour += (1 - fr) * sphere.material.specular * shade_legacy(reflected_ray, scene, depth - 1);
+		}
+	}
+	return total_colour + refraction_colour + reflection_colour; // :102
+}
+
+// --eval-legacy FILE: bp::fresnel / bp::refraction / bp::reflect_direction on 10 000 (direction, normal, ior) triples, inputs and
+// outputs as hex words, one triple per line.  The triples come from a fixed LCG: ray directions of length 0.5 .. 2 (primary rays are
+// not normalised, main.cpp:155), unit normals, ior in [0.5, 2.5] with every eighth exactly 1.
+static int eval_legacy(const char *path)
+{
+	FILE *f = fopen(path, "w");
+	if(!f) return 2;
+	uint64_t st = 0x9E3779B97F4A7C15ull;
+	auto unit = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float) ((st >> 40) & 0xFFFFFF) / 16777216.0f; };
+	for(int k = 0; k < 10000; k++)
+	{
+		glm::vec3 d(unit() * 2 - 1, unit() * 2 - 1, unit() * 2 - 1), n(unit() * 2 - 1, unit() * 2 - 1, unit() * 2 - 1);
+		if(glm::dot(d, d) < 1e-3f || glm::dot(n, n) < 1e-3f) { k--; continue; }
+		d = glm::normalize(d) * (0.5f + 1.5f * unit());
+		n = glm::normalize(n);
+		Sphere sphere;
+		sphere.material.ior = (k % 8 == 0) ? 1.0f : 0.5f + 2.0f * unit();
+		const float fr = bp::fresnel(d, n, sphere);
+		const glm::vec3 rf = bp::refraction(d, n, sphere), rl = bp::reflect_direction(glm::normalize(d), n);
+		hex3(f, d);
+		hex3(f, n);
+		hexf(f, sphere.material.ior);
+		hexf(f, fr);
+		hex3(f, rf);
+		hex3(f, rl);
+		fprintf(f, "\n");
+	}
+	fclose(f);
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	Options option;
 	const char *path = nullptr, *output = nullptr, *float_out = nullptr, *dump = nullptr;
 	int width = 1920, height = 1080; // scene.h:15 defaults, overridden by CLI (main.cpp:393-395)
-	bool use_shadows = false, parallel_entry = false, strict = false;
+	bool use_shadows = false, parallel_entry = false, strict = false, legacy = false;
 	unsigned seed = 1;
 
 	for(int i = 1; i < argc; i++)
@@ -147,6 +258,13 @@ int main(int argc, char **argv)
 		else if(!strcmp(argv[i], "--dump-scene")) dump = next();
 		else if(!strcmp(argv[i], "--parallel-entry")) parallel_entry = true;
 		else if(!strcmp(argv[i], "--strict")) strict = true;
+		else if(!strcmp(argv[i], "--legacy")) legacy = true;
+		else if(!strcmp(argv[i], "--eval-legacy")) return eval_legacy(next());
+	}
+	if(legacy && option.monte_carlo)
+	{
+		fprintf(stderr, "ref_render: --legacy is pinned without --gillum (montecarlo_global_illumination() calls the reference's own shade(), which leaves the mode)\n");
+		return 2;
 	}
 	if(!path || (!output && !dump))
 	{
@@ -249,7 +367,7 @@ int main(int argc, char **argv)
 						Ray ray;
 						ray.position  = scene.camera.position;
 						ray.direction = ray_dir; // main.cpp:155 discards the normalize() result
-						px += shade(ray, scene, option.max_depth, option.monte_carlo, option.num_path_traces);
+						px += legacy ? shade_legacy(ray, scene, option.max_depth) : shade(ray, scene, option.max_depth, option.monte_carlo, option.num_path_traces);
 					}
 				}
 				px /= (option.grid_size * option.grid_size);
@@ -262,7 +380,7 @@ int main(int argc, char **argv)
 				Ray ray;
 				ray.position  = scene.camera.position;
 				ray.direction = ray_dir;
-				px			  = shade(ray, scene, option.max_depth, option.monte_carlo, option.num_path_traces);
+				px			  = legacy ? shade_legacy(ray, scene, option.max_depth) : shade(ray, scene, option.max_depth, option.monte_carlo, option.num_path_traces);
 			}
 		}
 	}

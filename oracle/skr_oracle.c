@@ -434,6 +434,18 @@ static v3 legacy_reflect_direction(v3 L, v3 N)
 	return vnormalize(vsub(L, vscale(N, 2.0f * vdot(L, N))));
 }
 
+/* The three functions above on one (direction, normal, ior) triple, for the function-level pin against the reference's own
+ * (tests/golden/ref_legacy_eval.npy.gz, written by oracle/_ref/ref_render --eval-legacy): out = {fresnel, refraction.xyz,
+ * reflect_direction(normalize(dir), n).xyz}. */
+void sko_legacy_eval(const float d[3], const float n[3], float ior, float out[7])
+{
+	v3 dir = V(d[0], d[1], d[2]), N = V(n[0], n[1], n[2]);
+	out[0] = legacy_fresnel(dir, N, ior);
+	v3 rf = legacy_refraction(dir, N, ior), rl = legacy_reflect_direction(vnormalize(dir), N);
+	out[1] = rf.x; out[2] = rf.y; out[3] = rf.z;
+	out[4] = rl.x; out[5] = rl.y; out[6] = rl.z;
+}
+
 /* raytrace.h:45-103, the part of direct_illumination() behind its early return */
 static v3 legacy_terms(ctx_t *cx, v3 total_colour, v3 ray_dir, const sko_sphere *sp, v3 P, v3 N, int depth, uint32_t node)
 {

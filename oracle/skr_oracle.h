@@ -118,6 +118,7 @@ float sko_counter_jitter(uint64_t seed, uint32_t pixel, uint32_t aa);
 /* The primary ray direction the render loop forms for pixel (x, y): main.cpp:146-155 with the draw r (jitter != 0) or
  * :170-174 at the pixel centre.  The loop calls this very function. */
 void sko_primary_direction(const sko_scene *scene, int width, int height, float fov, int x, int y, int jitter, float r, float out[3]);
+void sko_legacy_eval(const float d[3], const float n[3], float ior, float out[7]); /* blinn_phong.h:156, :143, :137 restated: {fresnel, refraction, reflect_direction(normalize(d), n)} */
 int sko_write_ppm(const char *path, int w, int h, const uint8_t *rgb);
 
 #ifdef __cplusplus

@@ -11,7 +11,7 @@ EXPORTED_SYMBOLS = [
     "skr_scene_create_from_scn", "skr_scene_create_from_scn_ex", "skr_scene_create_from_arrays", "skr_scene_set_triangle_materials", "skr_scene_set_sphere_ior", "skr_scene_destroy", "skr_scene_get_info",
     "skr_scene_get_arrays", "skr_scene_get_culling", "skr_options_default", "skr_radiance_ray_count", "skr_device_count",
     "skr_renderer_create", "skr_renderer_destroy", "skr_render_tiles", "skr_tile_count", "skr_render_rows",
-    "skr_renderer_read_counters", "skr_renderer_read_work", "skr_renderer_reload_switches", "skr_renderer_kernel_timing", "skr_renderer_kernel_ms", "skr_renderer_last_parent_count", "skr_renderer_last_level1_count", "skr_render_frame_host", "skr_render_progressive_host", "skr_accumulate", "skr_resolve_accumulated", "skr_write_png", "skr_write_pfm", "skr_write_ppm", "skr_last_error",
+    "skr_renderer_read_counters", "skr_renderer_read_work", "skr_renderer_read_triangle_work", "skr_renderer_kernel_work", "skr_renderer_reload_switches", "skr_renderer_kernel_timing", "skr_renderer_kernel_ms", "skr_renderer_last_parent_count", "skr_renderer_last_level1_count", "skr_render_frame_host", "skr_render_progressive_host", "skr_accumulate", "skr_resolve_accumulated", "skr_write_png", "skr_write_pfm", "skr_write_ppm", "skr_last_error",
     "skr_kernel_variant", "skr_debug_eval",
     "skr_rccl_available", "skr_multi_create", "skr_multi_destroy", "skr_multi_device_count", "skr_multi_renderer", "skr_multi_render_frame",
     "skr_multi_render_frame_host", "skr_comm_unique_id", "skr_comm_create", "skr_comm_destroy", "skr_comm_render_frame", "skr_comm_render_frame_async", "skr_comm_flush", "skr_comm_frame_to_host",
@@ -89,6 +89,8 @@ def lib():
     L.skr_render_rows.argtypes = [vp, C.POINTER(COptions), C.c_uint32, C.c_uint32, vp, vp, vp]
     L.skr_renderer_read_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.skr_renderer_read_work.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+    L.skr_renderer_read_triangle_work.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+    L.skr_renderer_kernel_work.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.skr_renderer_reload_switches.argtypes = [vp]
     L.skr_renderer_kernel_timing.argtypes = [vp, C.c_int]
     L.skr_renderer_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
@@ -341,6 +343,18 @@ class Renderer:
         out = (C.c_uint64 * 4)()
         _check(lib().skr_renderer_read_work(self.h, out, int(reset)), "skr_renderer_read_work")
         return {"radiance_rays": int(out[0]), "sphere_hits": int(out[1]), "shadow_rays": int(out[2]), "sphere_tests": int(out[3])}
+
+    def kernel_work(self):
+        """work() of the one kernel kernel_ms() times, in the last launch made with kernel timing on (include/skr.h skr_renderer_kernel_work)."""
+        out = (C.c_uint64 * 4)()
+        _check(lib().skr_renderer_kernel_work(self.h, out), "skr_renderer_kernel_work")
+        return {"radiance_rays": int(out[0]), "sphere_hits": int(out[1]), "shadow_rays": int(out[2]), "sphere_tests": int(out[3])}
+
+    def triangle_work(self, reset=True):
+        """What the triangle walks executed (include/skr.h skr_renderer_read_triangle_work): call it BEFORE work(reset=True)."""
+        out = (C.c_uint64 * 3)()
+        _check(lib().skr_renderer_read_triangle_work(self.h, out, int(reset)), "skr_renderer_read_triangle_work")
+        return {"cull_tests": int(out[0]), "triangle_tests": int(out[1]), "reference_triangle_tests": int(out[2])}
 
     def kernel_timing(self, enable=True):
         _check(lib().skr_renderer_kernel_timing(self.h, int(enable)), "skr_renderer_kernel_timing")

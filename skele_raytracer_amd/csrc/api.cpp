@@ -47,7 +47,10 @@ struct skr_renderer {
 	int n_chunks = 0, chunk_size = 0, cones = 0;
 	size_t chunk_stride = 0;
 	unsigned long long *d_counters = nullptr;
+	unsigned long long *d_snap = nullptr; // skr_renderer_kernel_work: the work counters in front of and behind the dominant kernel of the last timed launch
+	unsigned long long *d_tri_work = nullptr; // 256 x {culling-sphere tests, triangle tests} executed by the triangle walks (skr_renderer_read_triangle_work)
 	int lds_limit = 0;
+	int pow_steps = 11; // bit length of the largest integer phong exponent in [1, 1024] among the scene's materials (device_math.h powf_spec)
 	// scratch of the parent-queue pipeline, grown on demand and kept
 	void *d_parents = nullptr;
 	void *d_levels = nullptr; // level-queue pipeline: level-1 hit records + level-1 slots
@@ -144,6 +147,15 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 		memcpy(&blob[r->off_kd], scene->sph_kd.data(), ns * 16);
 		memcpy(&blob[r->off_ks], scene->sph_ks.data(), ns * 16);
 	}
+	{ // the straight-line pow runs as many squarings as the scene's largest integer exponent has bits
+		float top = 1.0f;
+		auto look = [&](float pw) { if(pw >= 1.0f && pw <= 1024.0f && pw == rintf(pw) && pw > top) top = pw; };
+		for(size_t i = 0; i < ns; i++) look(scene->sph_amb[i].w);
+		for(size_t i = 0; i + 2 < scene->tri_mats.size(); i += 3) look(scene->tri_mats[i].w);
+		int bits = 0;
+		for(unsigned v = (unsigned) top; v; v >>= 1) bits++;
+		r->pow_steps = bits < 1 ? 1 : bits;
+	}
 	if(nl2) memcpy(&blob[r->off_lights], scene->lights.data(), nl2 * 16);
 	if(nt3) memcpy(&blob[r->off_tris], scene->tris.data(), nt3 * 16);
 	if(nch) memcpy(&blob[r->off_chunks], scene->tri_chunks.data(), nch * 16);
@@ -152,11 +164,14 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	if(e == hipSuccess) e = hipMemcpy(r->d_blob, blob.data(), blob.size() * 16, hipMemcpyHostToDevice);
 	if(e == hipSuccess) e = hipMalloc((void **) &r->d_counters, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long) + (SKR_PULL_QUEUES + 2 + 2 * SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t));
 	if(e == hipSuccess) e = hipMemset(r->d_counters, 0, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long) + (SKR_PULL_QUEUES + 2 + 2 * SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t));
+	if(e == hipSuccess) e = hipMalloc((void **) &r->d_tri_work, 256 * 2 * sizeof(unsigned long long));
+	if(e == hipSuccess) e = hipMemset(r->d_tri_work, 0, 256 * 2 * sizeof(unsigned long long));
 	if(e != hipSuccess)
 	{
 		skr_set_error("scene upload failed: %s", hipGetErrorString(e));
 		if(r->d_blob) (void) hipFree(r->d_blob);
 		if(r->d_counters) (void) hipFree(r->d_counters);
+		if(r->d_tri_work) (void) hipFree(r->d_tri_work);
 		delete r;
 		return SKR_ERR_HIP;
 	}
@@ -170,6 +185,8 @@ void skr_renderer_destroy(skr_renderer *r)
 	(void) hipSetDevice(r->device);
 	if(r->d_blob) (void) hipFree(r->d_blob);
 	if(r->d_counters) (void) hipFree(r->d_counters);
+	if(r->d_tri_work) (void) hipFree(r->d_tri_work);
+	if(r->d_snap) (void) hipFree(r->d_snap);
 	if(r->d_parents) (void) hipFree(r->d_parents);
 	if(r->d_levels) (void) hipFree(r->d_levels);
 	if(r->d_nodes) (void) hipFree(r->d_nodes);
@@ -276,6 +293,7 @@ static int render_pass(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.grid_size = opt->grid_size;
 	p.max_depth = opt->max_depth;
 	p.use_shadows = opt->use_shadows ? 1 : 0;
+	p.pow_steps = r->pow_steps;
 	// shade() only recurses under --gillum and only below a sphere hit (raytrace.h:208-218), and with N = 0 there is no
 	// child to recurse into: every --depth is then the depth-1 image
 	// (--shade-triangles: a triangle hit recurses too)
@@ -314,6 +332,7 @@ static int render_pass(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.rgb = d_rgb;
 	p.rgbf = d_rgbf;
 	p.counters = r->d_counters;
+	p.tri_work = r->d_tri_work;
 	p.qctr = reinterpret_cast<uint32_t *>(r->d_counters + (size_t) SKR_COUNTER_SHARDS * 4 + 8);
 	const bool nodes_path = skr_nodes_selected(p);
 	if(!nodes_path && p.max_depth > 6)
@@ -404,6 +423,13 @@ static int render_pass(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 			SKR_HIP(hipEventCreate(&hook.start));
 			SKR_HIP(hipEventCreate(&hook.stop));
 		}
+		if(!r->d_snap)
+		{
+			SKR_HIP(hipMalloc((void **) &r->d_snap, (size_t) 2 * SKR_COUNTER_SHARDS * 4 * sizeof(unsigned long long)));
+			SKR_HIP(hipMemset(r->d_snap, 0, (size_t) 2 * SKR_COUNTER_SHARDS * 4 * sizeof(unsigned long long)));
+		}
+		hook.snap = r->d_snap;
+		hook.counters = r->d_counters;
 	}
 	r->last_p = p;
 	r->last_nodes = nodes_path;
@@ -613,6 +639,41 @@ int skr_renderer_read_work(skr_renderer *r, uint64_t out[4], int reset)
 	if(rc != SKR_OK) return rc;
 	// every radiance ray tests every sphere (raytrace.h:152-165); a shadow ray stops at its first occluder (utils.h:52-55)
 	out[3] += out[0] * (uint64_t) r->info.n_spheres;
+	return SKR_OK;
+}
+
+int skr_renderer_kernel_work(skr_renderer *r, uint64_t out[4])
+{
+	if(!r || !out) return SKR_ERR_ARG;
+	for(int k = 0; k < 4; k++) out[k] = 0;
+	if(!r->d_snap) return SKR_OK;
+	SKR_HIP(hipSetDevice(r->device));
+	std::vector<unsigned long long> h((size_t) 2 * SKR_COUNTER_SHARDS * 4);
+	SKR_HIP(hipMemcpy(h.data(), r->d_snap, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost)); // synchronises with prior launches
+	const size_t half = (size_t) SKR_COUNTER_SHARDS * 4;
+	for(size_t s = 0; s < SKR_COUNTER_SHARDS; s++)
+		for(int k = 0; k < 4; k++) out[k] += h[half + 4 * s + k] - h[4 * s + k];
+	out[3] += out[0] * (uint64_t) r->info.n_spheres; // (as skr_renderer_read_work)
+	return SKR_OK;
+}
+
+int skr_renderer_read_triangle_work(skr_renderer *r, uint64_t out[3], int reset)
+{
+	if(!r || !out) return SKR_ERR_ARG;
+	SKR_HIP(hipSetDevice(r->device));
+	unsigned long long h[256 * 2];
+	SKR_HIP(hipMemcpy(h, r->d_tri_work, sizeof(h), hipMemcpyDeviceToHost)); // synchronises with prior launches
+	out[0] = out[1] = 0;
+	for(int s = 0; s < 256; s++)
+	{
+		out[0] += h[2 * s];
+		out[1] += h[2 * s + 1];
+	}
+	uint64_t w[4];
+	const int rc = read_work(r, w, 4, 0);
+	if(rc != SKR_OK) return rc;
+	out[2] = w[0] * (uint64_t) r->info.n_triangles; // raytrace.h:171-186: every radiance ray tests every triangle
+	if(reset) SKR_HIP(hipMemset(r->d_tri_work, 0, sizeof(h)));
 	return SKR_OK;
 }
 

@@ -42,6 +42,7 @@ SKR_DEV float sk_divf(float a, float b) { return a / b; }
 #ifndef SKR_FAST_EXACT
 #define SKR_FAST_EXACT 1
 #endif
+
 SKR_DEV bool mid_range_pos(float x) { return __float_as_uint(x) - (27u << 23) < (201u << 23); }                // 2^-100 <= x < 2^101
 SKR_DEV bool mid_range_abs(float x) { return (__float_as_uint(x) << 1) - (27u << 24) < (201u << 24); }         // 2^-100 <= |x| < 2^101
 SKR_DEV float sk_sqrtf(float x)
@@ -81,8 +82,38 @@ SKR_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 SKR_DEV f3 cross3(f3 x, f3 y) { return mk3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
 SKR_DEV float sqr3(f3 v) { return (v.x * v.x + v.y * v.y) + v.z * v.z; }
 SKR_DEV float length3(f3 v) { return sk_sqrtf(sqr3(v)); }
+// sqrt(ss), 1.0f / sqrt(ss) and 1.0f / (sqrt(ss) * sqrt(ss)) — a length, glm::normalize's factor and the 1 / d^2 of
+// blinn_phong.h:69-70 — behind ONE range test: for ss in [2^-98, 2^99) the length lies in [2^-49, 2^49.5] and its square in
+// [2^-98, 2^99.1], all inside the range the short exact forms are verified on.
+struct LenTerms { float len, inv, inv2; };
+template <bool WANT_INV2>
+SKR_DEV LenTerms len_terms(float ss)
+{
+	LenTerms t;
+#if SKR_FAST_EXACT
+	if(__builtin_expect(__float_as_uint(ss) - (29u << 23) < (197u << 23), 1))
+	{
+		const float y = __builtin_amdgcn_rsqf(ss);
+		const float s0 = ss * y, h = 0.5f * y;
+		t.len = __builtin_fmaf(__builtin_fmaf(-s0, s0, ss), h, s0);
+		const float r = __builtin_amdgcn_rcpf(t.len);
+		t.inv = __builtin_fmaf(__builtin_fmaf(-t.len, r, 1.0f), r, r);
+		t.inv2 = 0.0f;
+		if(WANT_INV2)
+		{
+			const float l2 = t.len * t.len, r2 = __builtin_amdgcn_rcpf(l2);
+			t.inv2 = __builtin_fmaf(__builtin_fmaf(-l2, r2, 1.0f), r2, r2);
+		}
+		return t;
+	}
+#endif
+	t.len = __builtin_sqrtf(ss);
+	t.inv = 1.0f / t.len;
+	t.inv2 = WANT_INV2 ? 1.0f / (t.len * t.len) : 0.0f;
+	return t;
+}
 // glm::normalize: v * (1.0f / sqrt(sum)) (func_geometric.inl:253-261, func_exponential.inl:226-229)
-SKR_DEV f3 normalize3(f3 v) { return v * sk_rcpf(sk_sqrtf(sqr3(v))); }
+SKR_DEV f3 normalize3(f3 v) { return v * len_terms<false>(sqr3(v)).inv; }
 // std::max(0.0f, x): NaN -> 0
 SKR_DEV float max0(float x) { return (0.0f < x) ? x : 0.0f; }
 SKR_DEV f3 ld3(const float4 v) { return mk3(v.x, v.y, v.z); }
@@ -259,8 +290,8 @@ static __device__ __attribute__((noinline)) float powf_general(float x, float p)
 
 // powf(x, p), x >= 0, in binary64, rounded once: square-and-multiply for integer p in [1,1024],
 // 2^(p log2 x) otherwise.
-SKR_DEV float powf_spec(float x, float p)
-{
+static __device__ __attribute__((noinline)) float powf_spec_cold(float x, float p)
+{ // every case the straight-line form below does not take: p == 0, NaN operands, negative x, a non-integer or huge exponent
 	if(p == 0.0f) return 1.0f;
 	if(x != x || p != p) return x + p;
 	if(x == 0.0f) return (p > 0.0f) ? 0.0f : __builtin_inff();
@@ -280,6 +311,39 @@ SKR_DEV float powf_spec(float x, float p)
 		return (float) r;
 	}
 	return powf_general(x, p);
+}
+
+// The common case — an integer exponent in [1, 1024] and 0 <= x <= inf — without a branch: the loop of the spec above runs as
+// many trips as the lane's exponent has bits, an s_cbranch each (~100 cycles of a wave's time apiece on this part, twice per
+// shaded hit); here 7 or 11 trips (by the bit length of the scene's largest integer exponent, RenderParams::pow_steps: wave-uniform)
+// are unrolled with a select where the spec has `if(n & 1)`.  The same products in the same order: squarings past a lane's top
+// bit are formed and never used; x = 0, 1, inf come out of the multiplications as the spec's early returns state them.
+#ifndef SKR_FLAT_POW
+#define SKR_FLAT_POW 1 // 0: the loop (A/B builds)
+#endif
+template <int STEPS>
+SKR_DEV float pow_int_flat(float x, unsigned n)
+{
+	double r = 1.0, base = (double) x;
+#pragma unroll
+	for(int k = 0; k < STEPS; k++)
+	{
+		const double rb = r * base;
+		r = ((n >> k) & 1u) ? rb : r;
+		if(k + 1 < STEPS) base *= base;
+	}
+	return (float) r;
+}
+SKR_DEV float powf_spec(float x, float p, int steps)
+{
+#if SKR_FLAT_POW
+	const bool plain = (p >= 1.0f) && (p <= 1024.0f) && (p == __builtin_rintf(p)) && (x >= 0.0f);
+	if(__builtin_expect(!plain, 0)) return powf_spec_cold(x, p);
+	// (`steps` is wave-uniform: one scalar branch picks the unrolled length — exponents below 128 in every shipped scene)
+	return steps <= 7 ? pow_int_flat<7>(x, (unsigned) p) : pow_int_flat<11>(x, (unsigned) p);
+#else
+	return powf_spec_cold(x, p);
+#endif
 }
 
 // ---------------------------------------------------------- geometry ----

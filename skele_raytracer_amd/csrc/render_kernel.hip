@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void skr_render_kernel(const RenderParams p)
 	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	__syncthreads();
 
-	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
+	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, p.n_tris, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work};
 
 	const int wave = tid >> 6, lane = tid & 63;
 	const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
@@ -469,15 +469,15 @@ hipError_t skr_launch_render(const RenderParams &p, hipStream_t stream, const ch
 			return skr_launch_queue(p, stream, hook);
 		}
 		*variant = "wave_streaming_v2";
-		if(hook && hook->start) (void) hipEventRecord(hook->start, stream);
+		skr_hook_start(hook, stream);
 		const hipError_t e = skr_launch_wave(p, stream);
-		if(hook && hook->stop) (void) hipEventRecord(hook->stop, stream);
+		skr_hook_stop(hook, stream);
 		return e;
 	}
 	const dim3 grid((p.width + 15) / 16, (p.out_rows + 15) / 16);
 	const size_t lds = skr_render_lds_bytes(p);
 	*variant = p.legacy_reflect ? "lane_per_pixel_legacy_v1r" : p.shade_triangles ? "lane_per_pixel_surfaces_v1s" : "lane_per_pixel_dfs_v1f";
-	if(hook && hook->start) (void) hipEventRecord(hook->start, stream);
+	skr_hook_start(hook, stream);
 	hipError_t e = hipErrorInvalidValue;
 	switch(p.max_depth)
 	{
@@ -489,7 +489,7 @@ hipError_t skr_launch_render(const RenderParams &p, hipStream_t stream, const ch
 		case 6: e = launch_depth<6>(p, grid, lds, stream); break;
 		default: break;
 	}
-	if(hook && hook->stop) (void) hipEventRecord(hook->stop, stream);
+	skr_hook_stop(hook, stream);
 	return e;
 }
 
@@ -540,7 +540,7 @@ __global__ void skr_debug_kernel(int op, const uint32_t *in, uint32_t *out, uint
 			out[2 * i + 1] = U(c);
 			break;
 		}
-		case 2: out[i] = U(powf_spec(F(in[2 * i]), F(in[2 * i + 1]))); break;
+		case 2: out[i] = U(powf_spec(F(in[2 * i]), F(in[2 * i + 1]), 11)); break;
 		case 3: {
 			const float a = F(in[3 * i]), b = F(in[3 * i + 1]), c = F(in[3 * i + 2]);
 			const float D = b * b - (4 * a) * c;

@@ -71,7 +71,7 @@ SKR_DEV SceneView stage_scene(const RenderParams &p, float4 *lds4, bool tris)
 	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
 	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	__syncthreads();
-	return SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, tris ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
+	return SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, tris ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work};
 }
 
 SKR_DEV void add_counters(const RenderParams &p, const Counters &cn, uint32_t shard, int lane)
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) SKR_TRACE_ATTR void skr_trace_kernel(const Ren
 		cn.rays += second ? 2u : 1u;
 		const RayPair rp = make_pair(d0, d1);
 		BestState s0, s1;
-		closest_pair_deferred(sv, co, d0, d1, second, rp, s0, s1);
+		closest_pair(sv, co, d0, d1, second, rp, s0, s1);
 		hit0 = classify_child(sv, co, d0, rp.two_a.x, rp.four_a.x, s0, black0);
 		rec0 = make_float4(__uint_as_float(node), __uint_as_float((uint32_t) (s0.best & 0xffff) | ((2u * j) << 16)), q1a, q2a);
 		if(second)
@@ -588,12 +588,7 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 				for(int c = 0; c < 2; c++) acc = acc + mk3(wrow[(3 * c) * cs], wrow[(3 * c + 1) * cs], wrow[(3 * c + 2) * cs]); // (rounds before the last have both children)
 				wave_lds_fence();
 			}
-			float *win = wrow;
-			if(q.count > NQ_PRE)
-			{ // room for the 128 hits this round can add (nothing but the nodes themselves is live here)
-				leaf_batch(sv, p, q, slots, co, lane, q.count < 64 ? q.count : 64, cn);
-				STAMP(3);
-			}
+			float *win = wrow; // (the ring has room for the 128 hits this round can add: the previous round left at most NQ_PRE waiting)
 			bool hit0 = false, hit1 = false;
 			f3 d0 = mk3(0, 0, 1), d1 = mk3(0, 0, 1);
 			float q1a = 0, q1b = 0;
@@ -614,7 +609,7 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 				cn.rays += second ? 2u : 1u;
 				const RayPair rp = make_pair(d0, d1);
 				BestState s0, s1;
-				closest_pair_deferred(sv, co, d0, d1, second, rp, s0, s1);
+				closest_pair(sv, co, d0, d1, second, rp, s0, s1);
 				bool black;
 				hit0 = classify_child(sv, co, d0, rp.two_a.x, rp.four_a.x, s0, black);
 				if(!hit0)
@@ -645,7 +640,7 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 			ring_push(q, hit1, d1, (uint32_t) (s1b & 0xffff) | idj | (1u << 22), q1b);
 			for(;;)
 			{
-				bool go = q.count >= 64;
+				bool go = q.count >= 64 || (!last && q.count > NQ_PRE); // a full batch; or room for the next round's 128 hits (one >= 3/4 full batch)
 				if(!go && q.count > 0)
 				{ // after the round: everything, if it was the last one; otherwise the hits of the round whose window the NEXT round reuses
 					go = last;
@@ -1021,9 +1016,9 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 				p.nd_src_level0 = 1;
 				p.nd_count = ctr0;
 				p.rc_ctr = lvl_ctr(0);
-				if(timed && hook->start) (void) hipEventRecord(hook->start, stream);
+				if(timed) skr_hook_start(hook, stream);
 				e = launch_leaf2<true>(p, lds_leaf, stream);
-				if(timed && hook->stop) (void) hipEventRecord(hook->stop, stream);
+				if(timed) skr_hook_stop(hook, stream);
 				if(e != hipSuccess) return e;
 				continue;
 			}
@@ -1039,7 +1034,7 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 				p.ixh = reinterpret_cast<uint4 *>(base + pl.off_ixh[L - 1]);
 				const uint64_t wg_t = (pl.nodes_max[L - 1] * (uint64_t) ((p.num_path_traces + 1) >> 1) + 255) / 256;
 				const unsigned grid_t = (unsigned) (wg_t < SKR_TRACE_GRID_MAX ? wg_t : SKR_TRACE_GRID_MAX);
-				if(flat && L == last && timed && hook->start) (void) hipEventRecord(hook->start, stream); // (flat: the last level's trace + shading are the dominant pair)
+				if(flat && L == last && timed) skr_hook_start(hook, stream); // (flat: the last level's trace + shading are the dominant pair)
 				if(tris) hipLaunchKernelGGL(skr_trace_kernel<true>, dim3(grid_t), dim3(256), lds_scene, stream, p);
 				else hipLaunchKernelGGL(skr_trace_kernel<false>, dim3(grid_t), dim3(256), lds_scene, stream, p);
 				if(L < last)
@@ -1058,13 +1053,13 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 				const unsigned grid_s = (unsigned) (wg < 16384 ? wg : 16384);
 				if(tris) hipLaunchKernelGGL(skr_shade_leaf_kernel<true>, dim3(grid_s), dim3(256), lds_scene, stream, p);
 				else hipLaunchKernelGGL(skr_shade_leaf_kernel<false>, dim3(grid_s), dim3(256), lds_scene, stream, p);
-				if(timed && hook->stop) (void) hipEventRecord(hook->stop, stream);
+				if(timed) skr_hook_stop(hook, stream);
 			}
 			else
 			{ // leaf kernel: the records of the last level (their parents: level last - 1), results into res[last]
-				if(timed && hook->start) (void) hipEventRecord(hook->start, stream);
+				if(timed) skr_hook_start(hook, stream);
 				e = launch_leaf2<false>(p, lds_leaf, stream);
-				if(timed && hook->stop) (void) hipEventRecord(hook->stop, stream);
+				if(timed) skr_hook_stop(hook, stream);
 				if(e != hipSuccess) return e;
 			}
 			for(int L = last - 1; L >= 0; L--)

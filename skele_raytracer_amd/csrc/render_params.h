@@ -58,10 +58,12 @@ struct RenderParams {
 	// utils.h:26-34 Options + scene.use_shadows
 	int32_t monte_carlo, num_path_traces, grid_size, max_depth, use_shadows;
 	uint32_t seed_lo, seed_hi;
+	int32_t pow_steps;        // bit length of the scene's largest integer phong exponent in [1, 1024] (device_math.h powf_spec): 1 .. 11
 	// outputs (device)
 	uint8_t *rgb;
 	float *rgbf;
 	unsigned long long *counters; // SKR_COUNTER_SHARDS x {radiance rays, sphere hits shaded, shadow rays, pad}
+	unsigned long long *tri_work; // 256 x {culling-sphere tests, triangle tests} the triangle walks executed (shade_common.h tri_work_add); null: not counted
 	// parent-queue pipeline (render_wave.hip: skr_primary_kernel -> skr_gi_kernel -> skr_resolve_kernel)
 	float4 *parents;    // 4 x float4 per primary hit: co.xyz N.x | N.yz direct.xy | direct.z kd.xyz | pixel, out_pix, -, -
 	uint32_t *qctr;     // [0] number of parents appended, [SKR_PULL_STRIDE * (1 + k)] next group of pull queue k
@@ -95,7 +97,23 @@ struct RenderParams {
 };
 
 // Optional timing of the dominant kernel of a launch (skr_renderer_kernel_ms): the launcher records the
-// two events right around that kernel on the launch stream.
+// two events right around that kernel on the launch stream — and, where `snap` is set, copies the work counters in front of the
+// first event and behind the second (stream-ordered device-to-device copies outside the timed window), so that the work of that
+// one kernel can be told from the frame's (skr_renderer_kernel_work: the numerator of bench.py's kernel-level roofline).
 struct SkrTimingHook {
 	hipEvent_t start = nullptr, stop = nullptr;
+	unsigned long long *snap = nullptr;             // device: 2 x SKR_COUNTER_SHARDS x 4 words, or null
+	const unsigned long long *counters = nullptr;   // device: RenderParams::counters
 };
+static inline void skr_hook_start(const SkrTimingHook *h, hipStream_t stream)
+{
+	if(!h) return;
+	if(h->snap) (void) hipMemcpyAsync(h->snap, h->counters, (size_t) SKR_COUNTER_SHARDS * 4 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream);
+	if(h->start) (void) hipEventRecord(h->start, stream);
+}
+static inline void skr_hook_stop(const SkrTimingHook *h, hipStream_t stream)
+{
+	if(!h) return;
+	if(h->stop) (void) hipEventRecord(h->stop, stream);
+	if(h->snap) (void) hipMemcpyAsync(h->snap + (size_t) SKR_COUNTER_SHARDS * 4, h->counters, (size_t) SKR_COUNTER_SHARDS * 4 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream);
+}

@@ -377,7 +377,7 @@ SKR_DEV PairOut child_round_pairs(const Wave &w, const ParSrc &par, int kbase, i
 		cn.rays += second ? 2u : 1u;
 		const RayPair rp = make_pair(d0, d1);
 		BestState s0, s1;
-		closest_pair_deferred(w.sv, co, d0, d1, second, rp, s0, s1);
+		closest_pair(w.sv, co, d0, d1, second, rp, s0, s1);
 		const int slot0 = sbase + k * (3 * w.N + 1) + 3 * i0;
 		po.hit0 = finish_child(w, co, d0, rp.two_a.x, rp.four_a.x, s0, kl, i0, r1a, slot0, po.h0);
 		if(second) po.hit1 = finish_child(w, co, d1, rp.two_a.y, rp.four_a.y, s1, kl, i1, r1b, slot0 + 3, po.h1);
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256, OCC) void skr_wave_kernel(const RenderParams p
 	using C = Cfg<OCC>;
 	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * (DEPTH == 1 ? C::DEPTH1_WAVE_FLOATS : C::WAVE_LDS_FLOATS);
 	Wave w;
-	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
+	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work};
 	w.p = &p;
 	w.slots = wbase;
 	w.lane = lane;
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256) SKR_PRIMARY_ATTR void skr_primary_kernel(const
 	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
 	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	__syncthreads();
-	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
+	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work};
 
 	const int wave = tid >> 6, lane = tid & 63;
 	const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(256, OCC) void skr_gi_kernel(const RenderParams p)
 	using C = Cfg<OCC, true>;
 	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * C::WAVE_LDS_FLOATS;
 	Wave w;
-	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
+	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work};
 	w.p = &p;
 	w.slots = wbase;
 	w.lane = lane;
@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(256) void skr_level1_kernel(const RenderParams p)
 	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
 	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	__syncthreads();
-	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
+	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work};
 	const int lane = tid & 63;
 	const uint32_t wave1 = (uint32_t) blockIdx.x * 4u + (uint32_t) (tid >> 6);
 	// one lane per sibling pair (children 2j, 2j+1 of a parent): one Philox call and one (e, c) per sphere for both
@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(256) void skr_level1_kernel(const RenderParams p)
 		cn.rays += second ? 2u : 1u;
 		const RayPair rp = make_pair(d0, d1);
 		BestState s0, s1;
-		closest_pair_deferred(sv, co, d0, d1, second, rp, s0, s1);
+		closest_pair(sv, co, d0, d1, second, rp, s0, s1);
 		const float pdf = (float) (1 / 3.14159265358979323846);
 #pragma nounroll
 		for(int c = 0; c < 2; c++)
@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(256, 4) void skr_leaf_kernel(const RenderParams p)
 #endif
 	float *wbase = reinterpret_cast<float *>(lds4 + 4 * ns + 1 + 2 * nl) + wave * LEAF_WAVE_FLOATS;
 	Wave w;
-	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones};
+	w.sv = SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work};
 	w.p = &p;
 	w.slots = wbase;
 	w.lane = lane;
@@ -1649,10 +1649,10 @@ hipError_t skr_launch_levels(const RenderParams &p_in, hipStream_t stream, const
 			if(tris) hipLaunchKernelGGL(skr_level1_kernel<true>, grid1, dim3(256), lds_scene, stream, p);
 			else hipLaunchKernelGGL(skr_level1_kernel<false>, grid1, dim3(256), lds_scene, stream, p);
 			// the leaf kernel is the dominant one: time it alone (the last band's launch when there are several)
-			if(hook && hook->start && last) (void) hipEventRecord(hook->start, stream);
+			if(last) skr_hook_start(hook, stream);
 			if(tris) hipLaunchKernelGGL(skr_leaf_kernel<true>, dim3(256u * 4u), dim3(256), lds_leaf, stream, p); // every workgroup resident
 			else hipLaunchKernelGGL(skr_leaf_kernel<false>, dim3(256u * 4u), dim3(256), lds_leaf, stream, p);
-			if(hook && hook->stop && last) (void) hipEventRecord(hook->stop, stream);
+			if(last) skr_hook_stop(hook, stream);
 			hipLaunchKernelGGL(skr_finalize_kernel, dim3((unsigned) ((pixels + 255) / 256)), dim3(256), 0, stream, p);
 			e = hipGetLastError();
 			if(e != hipSuccess) return e;
@@ -1702,10 +1702,10 @@ hipError_t skr_launch_queue(const RenderParams &p_in, hipStream_t stream, const 
 		e = hipGetLastError();
 		if(e != hipSuccess) return e;
 		// the GI kernel is the dominant one: time it alone (last sample's launch when there are several)
-		if(hook && hook->start && s == nsamp - 1) (void) hipEventRecord(hook->start, stream);
+		if(s == nsamp - 1) skr_hook_start(hook, stream);
 		if(p.max_depth == 2) e = occ3 ? launch_gi<2, 3>(p, lds2, stream) : launch_gi<2, 2>(p, lds2, stream);
 		else e = occ3 ? launch_gi<3, 3>(p, lds2, stream) : launch_gi<3, 2>(p, lds2, stream);
-		if(hook && hook->stop && s == nsamp - 1) (void) hipEventRecord(hook->stop, stream);
+		if(s == nsamp - 1) skr_hook_stop(hook, stream);
 		if(e != hipSuccess) return e;
 	}
 	if(p.grid_size > 0)

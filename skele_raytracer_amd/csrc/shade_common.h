@@ -24,7 +24,26 @@ struct SceneView {
 	int nchunks;          // nodes in the tree; 0 = walk every triangle
 	int chunk;            // triangles per chunk sphere (tri_chunks.h)
 	int cones;            // some entry carries a tight radius for non-grazing rays
+	unsigned long long *tri_work; // HBM, or null: SKR_TRI_WORK_SHARDS x {culling-sphere tests, triangle tests} the walks executed (lanes that needed them)
 };
+
+// What a triangle walk executed, counted per wave on the scalar unit (population counts of lane masks the walk forms anyway) and added
+// to one of SKR_TRI_WORK_SHARDS words by one lane when the walk ends: bench.py's FP32-VALU figure for mesh scenes is built from
+// these counts, not from the 10 002 tests per ray the reference's loop runs (raytrace.h:171-186).
+#define SKR_TRI_WORK_SHARDS 256u
+SKR_DEV void tri_work_add(const SceneView &sv, uint32_t n_cull, uint32_t n_tri)
+{
+	if(sv.tri_work && (n_cull | n_tri))
+	{
+		const unsigned long long m = __ballot(true);
+		if(__builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)) == 0)
+		{
+			unsigned long long *w = sv.tri_work + 2u * ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (SKR_TRI_WORK_SHARDS - 1u));
+			atomicAdd(&w[0], (unsigned long long) n_cull);
+			atomicAdd(&w[1], (unsigned long long) n_tri);
+		}
+	}
+}
 
 struct Counters {
 	uint32_t rays, hits, shadow_rays;
@@ -130,6 +149,7 @@ SKR_DEV bool tree_walk(const SceneView &sv, const RayConst &r, float tmin)
 	bool hit = false;
 	const float dd = r.two_a * 0.5f; // dot(d, d)
 	int i = 0;
+	uint32_t n_cull = 0, n_tri = 0; // (wave-uniform: scalar registers)
 	const float4 *chunk_ent = sv.chunks + 3 * (sv.nchunks + 1); // behind the nodes and their pad
 	float4 A = sv.chunks[0], B = sv.chunks[1], lk = sv.chunks[2];
 	while(i < sv.nchunks)
@@ -138,6 +158,7 @@ SKR_DEV bool tree_walk(const SceneView &sv, const RayConst &r, float tmin)
 		// first child (or the next node after a height-1 node) and next sibling (padded past the end)
 		const float4 A_in = sv.chunks[3 * i + 3], B_in = sv.chunks[3 * i + 4], lk_in = sv.chunks[3 * i + 5];
 		const float4 A_out = sv.chunks[3 * i_out], B_out = sv.chunks[3 * i_out + 1], lk_out = sv.chunks[3 * i_out + 2];
+		n_cull += (uint32_t) __popcll(__ballot(!hit));
 		const bool enter = __any(!hit && line_touches<CONES>(r, dd, A, B));
 		const int count = __float_as_int(lk.z);
 		if(enter && count > 0)
@@ -149,6 +170,7 @@ SKR_DEV bool tree_walk(const SceneView &sv, const RayConst &r, float tmin)
 				const float4 cA = cA_next, cB = cB_next;
 				cA_next = chunk_ent[2 * c + 2];
 				cB_next = chunk_ent[2 * c + 3];
+				n_cull += (uint32_t) __popcll(__ballot(!hit));
 				const bool mine = !hit && line_touches<CONES>(r, dd, cA, cB);
 				if(__any(mine))
 				{
@@ -161,6 +183,7 @@ SKR_DEV bool tree_walk(const SceneView &sv, const RayConst &r, float tmin)
 						n1 = sv.tris[3 * k + 4];
 						n2 = sv.tris[3 * k + 5];
 						float t;
+						n_tri += (uint32_t) __popcll(__ballot(mine && !hit));
 						if(mine && !hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
 					}
 				}
@@ -172,6 +195,7 @@ SKR_DEV bool tree_walk(const SceneView &sv, const RayConst &r, float tmin)
 		B = enter ? B_in : B_out;
 		lk = enter ? lk_in : lk_out;
 	}
+	tri_work_add(sv, n_cull, n_tri);
 	return hit;
 }
 
@@ -183,6 +207,7 @@ SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float t
 {
 	if(sv.nchunks > 0) return sv.cones ? tree_walk<true>(sv, r, tmin) : tree_walk<false>(sv, r, tmin);
 	bool hit = false;
+	uint32_t n_tri = 0;
 	// wave-uniform addresses => scalar loads; triangle i+1 is fetched while i is tested
 	// (tris[] carries one pad triangle so the prefetch needs no bounds test)
 	float4 n0 = sv.tris[0], n1 = sv.tris[1], n2 = sv.tris[2];
@@ -193,9 +218,11 @@ SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float t
 		n1 = sv.tris[3 * i + 4];
 		n2 = sv.tris[3 * i + 5];
 		float t;
+		n_tri += (uint32_t) __popcll(__ballot(!hit));
 		if(!hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
 		if((i & 7) == 7 && __all(hit)) break;
 	}
+	tri_work_add(sv, 0u, n_tri);
 	return hit;
 }
 
@@ -256,7 +283,7 @@ SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second,
 
 struct LightTerm { // the per-light quantities of blinn_phong.h:67-72 / :100-117
 	f3 L, lc;
-	float len;
+	float intensity; // 1 / powf(|Lp - P|, 2) (== 1 / (d * d): SURVEY.md 8c); exactly 1 for a directional light
 };
 
 SKR_DEV LightTerm light_term(const SceneView &sv, int i, f3 P)
@@ -265,15 +292,16 @@ SKR_DEV LightTerm light_term(const SceneView &sv, int i, f3 P)
 	const float4 lp4 = sv.lights[2 * i];
 	t.lc = ld3(sv.lights[2 * i + 1]);
 	if(lp4.w != 0.0f)
-	{ // a directional light (--strict-scn only; blinn_phong.h:81-82,126-128): L = normalize(direction) and no 1/d^2 — len = 1 makes
-	  // the intensity factor of the point-light expression exactly 1, and x * 1 == x
+	{ // a directional light (--strict-scn only; blinn_phong.h:81-82,126-128): L = normalize(direction) and no 1/d^2 — the intensity
+	  // factor of the point-light expression is exactly 1, and x * 1 == x
 		t.L = normalize3(ld3(lp4));
-		t.len = 1.0f;
+		t.intensity = 1.0f;
 		return t;
 	}
 	const f3 to_l = ld3(lp4) - P;
-	t.len = sk_sqrtf(sqr3(to_l));
-	t.L = to_l * sk_rcpf(t.len);
+	const LenTerms lt = len_terms<true>(sqr3(to_l));
+	t.L = to_l * lt.inv;
+	t.intensity = lt.inv2;
 	return t;
 }
 
@@ -294,23 +322,18 @@ SKR_DEV f3 direct_light_of(const SceneView &sv, const RenderParams &p, f3 kd, f3
 			cn.shadow_rays += second ? 2u : 1u;
 			occluded_pair(sv, P, t0.L, t1.L, second, occ0, occ1, cn.shadow_tests);
 		}
-#pragma nounroll
-		for(int k = 0; k < 2; k++)
-		{ // not unrolled: two interleaved binary64 pow evaluations would double the live registers
-			LightTerm t;
-			t.L = k ? t1.L : t0.L;
-			t.lc = k ? t1.lc : t0.lc;
-			t.len = k ? t1.len : t0.len;
-			const bool lit = k ? (second && !occ1) : !occ0;
+		auto add_light = [&](const LightTerm &t, bool lit)
+		{
 			if(lit)
 			{
-				const float intensity = sk_rcpf(t.len * t.len); // 1/powf(|d|,2) == 1/(d*d)
-				diffuse = diffuse + ((kd * t.lc) * intensity) * max0(dot3(N, t.L));
+				diffuse = diffuse + ((kd * t.lc) * t.intensity) * max0(dot3(N, t.L));
 				const f3 vl = view + t.L;
 				const f3 H = vl / length3(vl);
-				specular = specular + ((ks * t.lc) * intensity) * powf_spec(max0(dot3(N, H)), ambp.w);
+				specular = specular + ((ks * t.lc) * t.intensity) * powf_spec(max0(dot3(N, H)), ambp.w, p.pow_steps);
 			}
-		}
+		};
+		add_light(t0, !occ0);
+		add_light(t1, second && !occ1);
 	}
 	f3 total = mk3(0, 0, 0);
 	total = total + ld3(ambp);

@@ -122,6 +122,11 @@ SKR_DEV void closest_pair_deferred(const SceneView &sv, f3 o, f3 d0, f3 d1, bool
 }
 
 
+SKR_DEV void closest_pair(const SceneView &sv, f3 o, f3 d0, f3 d1, bool second, const RayPair &rp, BestState &s0, BestState &s1)
+{
+	closest_pair_deferred(sv, o, d0, d1, second, rp, s0, s1);
+}
+
 SKR_DEV void primary_ray(const RenderParams &p, int x, uint32_t y, uint32_t pixel, uint32_t aa, f3 &dir)
 { // main.cpp:140-182
 	float u, v;

@@ -61,6 +61,8 @@ def args_to_kwargs(args):
             kw["shadow"] = True
         elif a == "--strict":  # ref_driver.cpp: the directional lights pushed (--strict-scn)
             kw["strict"] = True
+        elif a == "--legacy":  # ref_driver.cpp: raytrace.h:45-103 runs (--legacy-reflect)
+            kw["legacy_reflect"] = True
         elif a == "--parallel-entry":  # main.cpp:21-24
             kw.update(width=640, height=480, depth=1, jsample=0)
     return kw

@@ -57,6 +57,13 @@ CASES = [
     ("spheres2_strict_shadow", "spheres2.scn", ["--width", "160", "--height", "90", "--shadow", "--strict"]),
     ("spheres2_strict_noshadow", "spheres2.scn", ["--width", "160", "--height", "90", "--strict"]),
     ("spheres2_strict_gi4", "spheres2.scn", ["--width", "96", "--height", "54", "--shadow", "--gillum", "4", "--strict", "--seed", "3"]),
+    # --legacy-reflect (round 3): ref_driver.cpp --legacy runs the control flow of raytrace.h:36-103 without its early
+    # return around the reference's own bp::fresnel / refraction / reflect_direction / ambient / diffuse / specular and its
+    # intersection functions (composition restated, every value the reference's)
+    ("spheres2_legacy_d2", "spheres2.scn", ["--width", "160", "--height", "90", "--depth", "2", "--legacy"]),
+    ("spheres2_legacy_d3_shadow", "spheres2.scn", ["--width", "160", "--height", "90", "--depth", "3", "--shadow", "--legacy"]),
+    ("spheres2_legacy_strict_d3", "spheres2.scn", ["--width", "96", "--height", "54", "--depth", "3", "--shadow", "--strict", "--legacy"]),
+    ("spheres1_legacy_d4", "spheres1.scn", ["--width", "96", "--height", "54", "--depth", "4", "--shadow", "--legacy"]),
 ]
 
 
@@ -99,6 +106,24 @@ def main():
         dst = os.path.join(GOLD, "scene_dump_%s.txt.gz" % scn[:-4])
         gz_write(d, dst)
         manifest["scene_dumps"][scn] = {"file": os.path.basename(dst), "sha256_uncompressed": sha(d)}
+    # bp::fresnel / bp::refraction / bp::reflect_direction themselves on 10 000 triples (ref_driver.cpp --eval-legacy): 14 words per triple
+    # [dir.xyz normal.xyz ior | fresnel | refraction.xyz | reflect_direction(normalize(dir), normal).xyz], kept as a uint32 array
+    try:
+        import io
+        import numpy as np
+        ev = "/tmp/golden_legacy_eval.txt"
+        subprocess.check_call([BIN, "--eval-legacy", ev])
+        words = np.array([[int(t, 16) for t in ln.split()] for ln in open(ev)], dtype=np.uint32)
+        assert words.shape == (10000, 14)
+        buf = io.BytesIO()
+        np.save(buf, words)
+        with open(os.path.join(GOLD, "ref_legacy_eval.npy.gz"), "wb") as f:
+            f.write(gzip.compress(buf.getvalue(), 9, mtime=0))
+        manifest["reference_fixture"]["ref_legacy_eval.npy.gz"] = {
+            "source": "oracle/_ref/ref_render --eval-legacy", "sha256_text": sha(ev),
+            "meaning": "the reference's bp::fresnel (blinn_phong.h:156), bp::refraction (:143), bp::reflect_direction (:137) on 10 000 (direction, normal, ior) triples"}
+    except ImportError:
+        print("numpy not importable: legacy eval fixture left as it is")
     # one of the reference's README pictures (a PNG screenshot, made when raytrace.h:45-103 still ran), box-filtered 4x: the visual
     # check of --legacy-reflect (tests/test_legacy_reflect.py).  Data only; PIL decodes the PNG.
     try:

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""HBM traffic of one headline frame over ALL its kernels from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
-`bench.py --steps 2 --warmup 1 --no-cpu-baseline`, written with the git blob hashes of the kernel sources it was measured on
-(bench.py reports it only while those hashes match).  Usage: pmc_traffic.py DIR_WITH_THE_TWO_PASSES OUT.json"""
+"""HBM traffic of one frame over ALL its kernels from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
+`bench.py [--config C] --steps 2 --warmup 1 --no-cpu-baseline`, written with the git blob hashes of the kernel sources it was
+measured on (bench.py reports it only while those hashes match).  Every dispatch of every skr_ kernel is summed and divided by the
+frames that command renders (1 warm-up + 2 timed + 3 of the kernel-timing pass = 6), so configurations whose frame takes several
+launches of a kernel (AA samples, bands) are counted whole.
+Usage: pmc_traffic.py DIR_WITH_THE_TWO_PASSES OUT.json [CONFIG [VARIANT]]"""
 import csv, glob, json, os, sys
 from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,23 +12,25 @@ sys.path.insert(0, ROOT)
 import bench
 
 root, out = sys.argv[1], sys.argv[2]
-acc = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> per-dispatch values
+config = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+variant = sys.argv[4] if len(sys.argv) > 4 else ("node_levels_v5" if config in (3, 5) else "wave_streaming_v2")
+FRAMES = 6
+acc = defaultdict(lambda: defaultdict(float))   # kernel -> counter -> sum over dispatches
+launches = defaultdict(set)
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
-    per = defaultdict(float)
     with open(f) as fh:
         for row in csv.DictReader(fh):
             if "skr_" in row["Kernel_Name"] and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
-                per[(row["Kernel_Name"], row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"])
-    for (k, d, c), v in per.items():
-        acc[k][c].append(v)
+                acc[row["Kernel_Name"]][row["Counter_Name"]] += float(row["Counter_Value"])
+                launches[(row["Kernel_Name"], row["Counter_Name"])].add(row["Dispatch_Id"])
 per_kernel, total = {}, 0.0
 for k, cs in sorted(acc.items()):
-    fetch = sum(cs["FETCH_SIZE"]) / max(1, len(cs["FETCH_SIZE"]))   # KiB per launch (one launch of each kernel per frame)
-    write = sum(cs["WRITE_SIZE"]) / max(1, len(cs["WRITE_SIZE"]))
+    fetch, write = cs["FETCH_SIZE"] / FRAMES, cs["WRITE_SIZE"] / FRAMES   # KiB per frame
     b = (2.0 * fetch + write) * 1024.0  # MI355X_MICROARCH.md HBM: FETCH_SIZE reports half the bytes of a coalesced read stream on gfx950
-    per_kernel[k.replace("void ", "").replace("(RenderParams)", "")] = {"fetch_kib": fetch, "write_kib": write, "bytes": b}
+    per_kernel[k.replace("void ", "").replace("(RenderParams)", "")] = {"fetch_kib": fetch, "write_kib": write, "bytes": b, "launches_per_frame": len(launches[(k, "FETCH_SIZE")]) / FRAMES}
     total += b
-json.dump({"variant": "node_levels_v5", "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (separate passes: tools/pmc_pass.sh)",
+json.dump({"variant": variant, "config": config,
+           "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --output-format csv -- python3 bench.py --config %d --steps 2 --warmup 1 --no-cpu-baseline (separate passes: tools/pmc_pass.sh); per frame = all dispatches / %d frames" % (config, FRAMES),
            "correction": "MI355X_MICROARCH.md HBM: FETCH_SIZE doubled (gfx950 reports half of a coalesced read stream), WRITE_SIZE as is; KiB -> bytes",
            "per_kernel": per_kernel, "traffic_bytes_per_frame": total, "sources": bench.source_hashes()}, open(out, "w"), indent=1)
 print(json.dumps(per_kernel, indent=1)); print("total MB per frame: %.1f" % (total / 1e6))

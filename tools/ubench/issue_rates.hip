@@ -147,6 +147,26 @@ __global__ __launch_bounds__(256) void k(unsigned long long *out, float seed, in
 #define X(i) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(dd[i]) : "v"(dd[(i + 1) & 15]));
 			REP16(X) REP16(X) REP16(X) REP16(X) REP16(X) REP16(X) REP16(X) REP16(X)
 #undef X
+		} else if(OP == 26) { // 128 v_mul per trip with a TAKEN forward branch (to the very next instruction) after every 16
+#define X(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r[i]) : "v"(seed));
+#define BR(n) asm volatile("s_cmp_eq_u32 0, 0\n\ts_cbranch_scc1 .Lt" #n "_%=\n\ts_nop 0\n.Lt" #n "_%=:" : : : "scc");
+			REP16(X) BR(0) REP16(X) BR(1) REP16(X) BR(2) REP16(X) BR(3) REP16(X) BR(4) REP16(X) BR(5) REP16(X) BR(6) REP16(X) BR(7)
+#undef BR
+#undef X
+		} else if(OP == 27) { // the same with the branches NOT taken
+#define X(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r[i]) : "v"(seed));
+#define BR(n) asm volatile("s_cmp_eq_u32 0, 1\n\ts_cbranch_scc1 .Ln" #n "_%=\n\ts_nop 0\n.Ln" #n "_%=:" : : : "scc");
+			REP16(X) BR(0) REP16(X) BR(1) REP16(X) BR(2) REP16(X) BR(3) REP16(X) BR(4) REP16(X) BR(5) REP16(X) BR(6) REP16(X) BR(7)
+#undef BR
+#undef X
+		} else if(OP == 28) { // 128 v_mul per trip, 64 of them issued with EXEC = 0 (what an un-skipped divergent block costs when no lane is in it)
+#define X(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r[i]) : "v"(seed));
+#define OFF asm volatile("s_mov_b64 s[20:21], exec\n\ts_mov_b64 exec, 0" : : : "s20", "s21");
+#define ON asm volatile("s_mov_b64 exec, s[20:21]" : : : "s20", "s21");
+			REP16(X) OFF REP16(X) ON REP16(X) OFF REP16(X) ON REP16(X) OFF REP16(X) ON REP16(X) OFF REP16(X) ON
+#undef OFF
+#undef ON
+#undef X
 		} else if(OP == 21) { // the closest-hit sphere loop's mix (render_nodes.hip closest_pair_deferred, main path of one trip): 9 plain + 9 packed + 4 compares
 			asm volatile("v_sub_f32 %0, %0, %1\n\tv_pk_mul_f32 %2, %2, %3\n\tv_mul_f32 %4, %4, %1\n\tv_pk_add_f32 %5, %5, %3\n\tv_add_f32 %0, %0, %4\n\tv_pk_mul_f32 %2, %2, %5\n\tv_cmp_le_f32 vcc, 0, %0\n\tv_pk_add_f32 %3, %3, %2"
 						 : "+v"(r[0]), "+v"(r[1]), "+v"(p[0]), "+v"(p[1]), "+v"(r[2]), "+v"(p[2]) : : "vcc");
@@ -263,6 +283,10 @@ int main(int argc, char **argv)
 	run<23>("v_fma_f32 x128", 128);
 	run<24>("v_pk_fma_f32 x128", 128);
 	run<25>("v_fma_f64 x128", 128);
+	run<26>("x128 +8 taken br", 128);
+	run<27>("x128 +8 untaken", 128);
+	run<28>("x128 half EXEC=0", 128);
+	if(quick) return 0;
 	run<0>("v_mul_f32");
 	run<9>("v_fma_f32");
 	run<20>("v_fma_f32 dep.");
