@@ -10,7 +10,7 @@ LIBDIR  := skele_raytracer_amd/lib
 # float divide/sqrt stay correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
             -fno-fast-math -Wall -Wno-unused-function -Wno-pass-failed -Iinclude
-KERNEL_SRCS := $(CSRC)/render_kernel.hip $(CSRC)/render_wave.hip $(CSRC)/render_nodes.hip $(CSRC)/accumulate.hip
+KERNEL_SRCS := $(CSRC)/render_kernel.hip $(CSRC)/render_wave.hip $(CSRC)/render_nodes.hip $(CSRC)/render_generic.hip $(CSRC)/accumulate.hip
 HOST_SRCS   := $(CSRC)/api.cpp $(CSRC)/scene_host.cpp $(CSRC)/multi_gpu.cpp
 HDRS        := include/skr.h $(CSRC)/device_math.h $(CSRC)/shade_common.h $(CSRC)/render_params.h $(CSRC)/scene_host.h $(CSRC)/tri_chunks.h $(CSRC)/wave_common.h
 
@@ -20,9 +20,9 @@ lib: $(LIBDIR)/libskr.so
 cli: bin/raytracer
 
 OBJDIR := build/obj
-OBJS   := $(OBJDIR)/render_kernel.o $(OBJDIR)/render_wave.o $(OBJDIR)/render_nodes.o $(OBJDIR)/accumulate.o $(OBJDIR)/api.o $(OBJDIR)/scene_host.o $(OBJDIR)/multi_gpu.o
+OBJS   := $(OBJDIR)/render_kernel.o $(OBJDIR)/render_wave.o $(OBJDIR)/render_nodes.o $(OBJDIR)/render_generic.o $(OBJDIR)/accumulate.o $(OBJDIR)/api.o $(OBJDIR)/scene_host.o $(OBJDIR)/multi_gpu.o
 
-# one object per translation unit (the three kernel files take a minute each: `make -j4 lib`)
+# one object per translation unit (the kernel files take a minute or two each: `make -j4 lib`)
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(EXTRA) -c -o $@ $<
@@ -47,6 +47,7 @@ asm: $(KERNEL_SRCS) $(HDRS)
 	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S -o build/render_kernel.s $(CSRC)/render_kernel.hip -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt
 	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S -o build/render_wave.s $(CSRC)/render_wave.hip -Rpass-analysis=kernel-resource-usage 2>> build/resource_usage.txt
 	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S -o build/render_nodes.s $(CSRC)/render_nodes.hip -Rpass-analysis=kernel-resource-usage 2>> build/resource_usage.txt
+	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S -o build/render_generic.s $(CSRC)/render_generic.hip -Rpass-analysis=kernel-resource-usage 2>> build/resource_usage.txt
 
 clean:
 	rm -rf $(LIBDIR) bin build

@@ -52,10 +52,10 @@ VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
 # triangle walk (shade_common.h line_touches: cross, dot, one product, one compare) is 19
 FLOP_SPHERE_TEST, FLOP_TRI_TEST, FLOP_TRI_TEST_REF, FLOP_CULL_TEST, FLOP_SHADED_HIT = 34, 46, 58, 19, 150
 # the files whose contents decide what the kernels move: the measured traffic is only reported for the exact sources it was measured on
-KERNEL_SOURCES = ["skele_raytracer_amd/csrc/render_nodes.hip", "skele_raytracer_amd/csrc/render_wave.hip", "skele_raytracer_amd/csrc/wave_common.h",
+KERNEL_SOURCES = ["skele_raytracer_amd/csrc/render_nodes.hip", "skele_raytracer_amd/csrc/render_wave.hip", "skele_raytracer_amd/csrc/render_generic.hip", "skele_raytracer_amd/csrc/wave_common.h",
                   "skele_raytracer_amd/csrc/shade_common.h", "skele_raytracer_amd/csrc/device_math.h", "skele_raytracer_amd/csrc/render_params.h"]
 DOMINANT = {"node_levels_v5": "skr_leaf_kernel2<false, false>", "node_levels_v5_flat": "skr_trace_kernel<false> (last level) + skr_shade_leaf_kernel<false>",
-            "wave_streaming_v2": "skr_wave_kernel<1, 3>"}
+            "direct_v3": "skr_direct_kernel", "level_pipeline_g1": "skr_gtrace_kernel + skr_gactivate_kernel + skr_gfinalize_kernel (all levels of the last band)"}
 
 
 def traffic_json(config):
@@ -287,7 +287,6 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    r.triangle_work(reset=True)
     r.work(reset=True)
     sync()
     t0 = time.perf_counter()
@@ -299,7 +298,6 @@ def main():
     variant = r.kernel_variant()
     queued = r.last_parent_count()
     level1 = r.last_level1_count()
-    tri = r.triangle_work(reset=True)   # (before the counters it scales are reset)
     cnt = r.work(reset=True)
     # the dominant kernel alone: HIP events on its stream around every launch of a short extra pass (not in the timed region),
     # and the work counters copied in front of and behind it (skr_renderer_kernel_work)
@@ -320,8 +318,19 @@ def main():
     kwork = r.kernel_work()
     r.kernel_timing(False)
     pipeline_ms = e0.elapsed_time(e1) / n_probe  # everything this rank enqueues per frame before the collective
-    r.triangle_work(reset=True)
     r.work(reset=True)
+    # what the triangle walks execute, from ONE frame rendered with the walks counting (never a timed frame: counting costs the dragon
+    # walk ~19 %); scaled to the timed frames below (every frame of a run is the same frame)
+    tri = {"cull_tests": 0, "triangle_tests": 0, "reference_triangle_tests": 0}
+    if scene.info.n_triangles > 0:
+        r.count_triangle_work(True)
+        r.triangle_work(reset=True)
+        r.render_tiles_into(opt, TILE_ROWS, rank, world, probe.data_ptr(), None, stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        tri = r.triangle_work(reset=True)
+        r.count_triangle_work(False)
+        r.work(reset=True)
+        tri = {k: v * args.steps for k, v in tri.items()}
 
     stats = torch.tensor([dt, float(cnt["radiance_rays"]), float(cnt["shadow_rays"]), float(cnt["sphere_hits"]), float(cnt["sphere_tests"]), kernel_ms, pipeline_ms,
                           float(tri["cull_tests"]), float(tri["triangle_tests"]), float(tri["reference_triangle_tests"])],
@@ -364,7 +373,7 @@ def main():
         frame_tflops = frame_flop / (ms_per_step * 1e-3) / 1e12 / world
         # the dominant kernel's own share (skr_renderer_kernel_work: counters copied around it; mesh walks are not split per kernel: whole-frame
         # figure where the wave kernel IS the frame).  The wave kernel traces all the AA samples of a frame in one launch.
-        whole_frame_kernel = variant == "wave_streaming_v2"
+        whole_frame_kernel = variant == "direct_v3"
         if whole_frame_kernel:
             kernel_flop = frame_flop
         else:

@@ -163,6 +163,14 @@ void skr_renderer_destroy(skr_renderer *r);
  * depend on the partition. */
 int skr_render_tiles(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t first_tile,
 					 uint32_t tile_stride, uint8_t *d_rgb, float *d_rgbf, void *stream);
+/* The same for an explicit list of tiles: slot k of the compact output (rows k*tile_rows ..) holds tile d_tiles[k] — a DEVICE array
+ * of n_slots tile indices, 0xFFFFFFFF = an empty slot (its rows are left untouched).  What the multi-GPU frame steps render with
+ * once the tiles are dealt by cost instead of by `t mod G`. */
+int skr_render_tile_list(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, const uint32_t *d_tiles, uint32_t n_slots,
+						 uint8_t *d_rgb, float *d_rgbf, void *stream);
+/* Per tile of tile_rows image rows, the number of its pixels whose primary ray ends on a sphere (the pixels under which a --gillum
+ * tree grows): the cost estimate behind the multi-GPU tile map.  Synchronous; h_hits has ceil(height / tile_rows) entries. */
+int skr_tile_costs(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t *h_hits);
 /* Number of tiles / output rows skr_render_tiles will produce for this partition. */
 uint32_t skr_tile_count(const skr_options *opt, uint32_t tile_rows, uint32_t first_tile, uint32_t tile_stride);
 /* Contiguous rows [y0, y1) (one tile of y1-y0 rows starting at y0). */
@@ -185,7 +193,10 @@ int skr_renderer_read_work(skr_renderer *r, uint64_t out[4], int reset);
  * timing on: the counters are copied on the launch stream in front of and behind that kernel, outside the timed window.  Do not
  * reset the counters between that launch and this call.  Synchronous. */
 int skr_renderer_kernel_work(skr_renderer *r, uint64_t out[4]);
-/* What the triangle walks did since the last reset (synchronous; read it BEFORE resetting the counters above): out[0] culling-sphere
+/* The triangle walks count what they execute only while this is on (off at creation): counting costs the dragon walk ~19 %, so a
+ * measurement takes its counts from frames rendered for that purpose and its times from frames rendered without. */
+int skr_renderer_count_triangle_work(skr_renderer *r, int enable);
+/* What the triangle walks did while counting since the last reset (synchronous; read it BEFORE resetting the counters above): out[0] culling-sphere
  * tests and out[1] ray-triangle tests (utils.h:181-213) the kernels executed — lanes that needed the test, counted by the walks
  * themselves —, out[2] the ray-triangle tests the reference's loop runs for the same rays (raytrace.h:171-186: every triangle for
  * every radiance ray).  bench.py prices mesh scenes with out[0] and out[1]; out[2] / out[1] is what the exact culling saves. */
@@ -218,10 +229,12 @@ int skr_render_progressive_host(skr_renderer *r, const skr_options *opt, uint32_
 /* ---- multi-GPU: the frame sharded over the GPUs of one node ----
  * Replaces the reference's only parallel entry, `generate_rays_parallel` (main.cpp:19-104: `#pragma omp parallel for`
  * over the rows at :33, dispatched at main.cpp:402-410) — the reference has no distributed path.
- * The framebuffer is cut into tiles of tile_rows rows, tile t belongs to rank t mod G; every rank renders its tiles
- * (skr_render_tiles, first_tile = rank, tile_stride = G) straight into its slot of a gather buffer, ONE RCCL
- * all-gather over xGMI brings the slots together and rank 0 de-interleaves on the device.  The image does not
- * depend on G.  RCCL is bound at run time; skr_rccl_available() says whether it could be. */
+ * The framebuffer is cut into tiles of tile_rows rows; the tiles are dealt to the ranks by estimated cost (longest processing time
+ * first over skr_tile_costs: sky tiles cost one ray per pixel, ground tiles a whole tree — skr_shard_plan; SKR_SHARD=interleave
+ * in the environment restores rounds 1-2's `tile t to rank t mod G`); every rank renders its tiles (skr_render_tile_list) straight
+ * into its slot of a gather buffer, ONE RCCL all-gather over xGMI brings the slots together and rank 0 de-interleaves on the device.
+ * The image does not depend on G or on the map (the RNG is keyed by the global pixel).  RCCL is bound at run time;
+ * skr_rccl_available() says whether it could be. */
 int skr_rccl_available(void);
 /* (a) ONE process, N devices (ncclCommInitAll; a renderer, a stream and a worker thread per device).
  * devices == NULL: devices 0 .. n_devices-1.  What `raytracer --gpus N` uses. */
@@ -234,6 +247,12 @@ skr_renderer *skr_multi_renderer(skr_multi *m, int i); /* device i's renderer (c
  * frame_ms: first launch to de-interleaved frame, on the root's stream. */
 int skr_multi_render_frame(skr_multi *m, const skr_options *opt, uint32_t tile_rows, uint8_t **d_frame, float *frame_ms);
 int skr_multi_render_frame_host(skr_multi *m, const skr_options *opt, uint32_t tile_rows, uint8_t *h_rgb, float *frame_ms);
+/* The pipelined form (throughput of a run of frames; what skr_comm_render_frame_async is to shape (b)): frame f's all-gather and
+ * de-interleave go to a second stream per device while the render streams take frame f + 1 into the other of two buffer sets.
+ * Returns once frame f is enqueued; *d_prev_frame = the PREVIOUS call's frame, complete (NULL on the first call; pass NULL not to
+ * wait for it).  skr_multi_flush waits for everything in flight; *d_frame = the last frame. */
+int skr_multi_render_frame_async(skr_multi *m, const skr_options *opt, uint32_t tile_rows, uint8_t **d_prev_frame);
+int skr_multi_flush(skr_multi *m, uint8_t **d_frame);
 /* (b) one process PER device (torchrun, mpirun): rank 0 makes an id, the caller broadcasts it by whatever transport
  * it has, every rank creates its communicator on its renderer's device.  id == NULL with world == 1: no RCCL at all. */
 #define SKR_COMM_ID_BYTES 128
@@ -257,6 +276,13 @@ int skr_comm_frame_to_host(skr_comm *c, uint8_t *h_rgb, void *stream);
  * buffer [world][tiles_per_rank * tile_rows][W*3] into frame[H][W*3]. */
 uint32_t skr_shard_tiles_per_rank(int32_t height, uint32_t tile_rows, uint32_t world);
 int skr_shard_deinterleave_host(const uint8_t *gathered, uint8_t *frame, int32_t width, int32_t height, uint32_t tile_rows, uint32_t world);
+/* The cost-aware map: slot_of_tile[t] = rank * k_max + slot (k_max = skr_shard_tiles_per_rank) for n_tiles tiles of cost[t] each —
+ * most expensive first, each to the least loaded rank with a free slot; deterministic.  skr_shard_plan: the map a frame step of
+ * `world` ranks uses for this renderer and these options (the probe + the deal).  skr_shard_deinterleave_map_host: the
+ * de-interleave under such a map. */
+int skr_shard_lpt(const uint64_t *cost, uint32_t n_tiles, uint32_t world, uint32_t *slot_of_tile);
+int skr_shard_plan(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t world, uint32_t *slot_of_tile);
+int skr_shard_deinterleave_map_host(const uint8_t *gathered, uint8_t *frame, int32_t width, int32_t height, uint32_t tile_rows, const uint32_t *slot_of_tile);
 
 /* ---- image file: replaces the inline writer main.cpp:199-211 ---- */
 int skr_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb);

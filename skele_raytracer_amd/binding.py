@@ -10,12 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 EXPORTED_SYMBOLS = [
     "skr_scene_create_from_scn", "skr_scene_create_from_scn_ex", "skr_scene_create_from_arrays", "skr_scene_set_triangle_materials", "skr_scene_set_sphere_ior", "skr_scene_destroy", "skr_scene_get_info",
     "skr_scene_get_arrays", "skr_scene_get_culling", "skr_options_default", "skr_radiance_ray_count", "skr_device_count",
-    "skr_renderer_create", "skr_renderer_destroy", "skr_render_tiles", "skr_tile_count", "skr_render_rows",
-    "skr_renderer_read_counters", "skr_renderer_read_work", "skr_renderer_read_triangle_work", "skr_renderer_kernel_work", "skr_renderer_reload_switches", "skr_renderer_kernel_timing", "skr_renderer_kernel_ms", "skr_renderer_last_parent_count", "skr_renderer_last_level1_count", "skr_render_frame_host", "skr_render_progressive_host", "skr_accumulate", "skr_resolve_accumulated", "skr_write_png", "skr_write_pfm", "skr_write_ppm", "skr_last_error",
+    "skr_renderer_create", "skr_renderer_destroy", "skr_render_tiles", "skr_render_tile_list", "skr_tile_costs", "skr_tile_count", "skr_render_rows",
+    "skr_renderer_read_counters", "skr_renderer_read_work", "skr_renderer_read_triangle_work", "skr_renderer_count_triangle_work", "skr_renderer_kernel_work", "skr_renderer_reload_switches", "skr_renderer_kernel_timing", "skr_renderer_kernel_ms", "skr_renderer_last_parent_count", "skr_renderer_last_level1_count", "skr_render_frame_host", "skr_render_progressive_host", "skr_accumulate", "skr_resolve_accumulated", "skr_write_png", "skr_write_pfm", "skr_write_ppm", "skr_last_error",
     "skr_kernel_variant", "skr_debug_eval",
     "skr_rccl_available", "skr_multi_create", "skr_multi_destroy", "skr_multi_device_count", "skr_multi_renderer", "skr_multi_render_frame",
     "skr_multi_render_frame_host", "skr_comm_unique_id", "skr_comm_create", "skr_comm_destroy", "skr_comm_render_frame", "skr_comm_render_frame_async", "skr_comm_flush", "skr_comm_frame_to_host",
-    "skr_shard_tiles_per_rank", "skr_shard_deinterleave_host",
+    "skr_shard_tiles_per_rank", "skr_shard_deinterleave_host", "skr_shard_lpt", "skr_shard_plan", "skr_shard_deinterleave_map_host", "skr_multi_render_frame_async", "skr_multi_flush",
 ]
 
 
@@ -91,6 +91,7 @@ def lib():
     L.skr_renderer_read_work.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.skr_renderer_read_triangle_work.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.skr_renderer_kernel_work.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.skr_renderer_count_triangle_work.argtypes = [vp, C.c_int]
     L.skr_renderer_reload_switches.argtypes = [vp]
     L.skr_renderer_kernel_timing.argtypes = [vp, C.c_int]
     L.skr_renderer_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
@@ -123,6 +124,13 @@ def lib():
     L.skr_comm_frame_to_host.argtypes = [vp, vp, vp]
     L.skr_comm_render_frame_async.argtypes = [vp, C.POINTER(COptions), C.c_uint32, C.POINTER(vp), vp]
     L.skr_comm_flush.argtypes = [vp, C.POINTER(vp), vp]
+    L.skr_multi_render_frame_async.argtypes = [vp, C.POINTER(COptions), C.c_uint32, C.POINTER(vp)]
+    L.skr_multi_flush.argtypes = [vp, C.POINTER(vp)]
+    L.skr_render_tile_list.argtypes = [vp, C.POINTER(COptions), C.c_uint32, vp, C.c_uint32, vp, vp, vp]
+    L.skr_tile_costs.argtypes = [vp, C.POINTER(COptions), C.c_uint32, vp]
+    L.skr_shard_lpt.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.skr_shard_plan.argtypes = [vp, C.POINTER(COptions), C.c_uint32, C.c_uint32, vp]
+    L.skr_shard_deinterleave_map_host.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_uint32, vp]
     L.skr_shard_tiles_per_rank.argtypes = [C.c_int32, C.c_uint32, C.c_uint32]
     L.skr_shard_tiles_per_rank.restype = C.c_uint32
     L.skr_shard_deinterleave_host.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32]
@@ -292,6 +300,25 @@ class Renderer:
         _check(lib().skr_render_tiles(self.h, C.byref(opt.c), tile_rows, first_tile, tile_stride, rgb_ptr, rgbf_ptr,
                                       stream), "skr_render_tiles")
 
+    def render_tile_list_into(self, opt, tile_rows, tiles_ptr, n_slots, rgb_ptr, rgbf_ptr=None, stream=None):
+        """skr_render_tile_list: slot k of the compact output holds tile tiles[k] (a device array of uint32; 0xFFFFFFFF = empty)."""
+        self._sync_switches()
+        _check(lib().skr_render_tile_list(self.h, C.byref(opt.c), tile_rows, tiles_ptr, n_slots, rgb_ptr, rgbf_ptr, stream), "skr_render_tile_list")
+
+    def tile_costs(self, opt, tile_rows):
+        """Per tile, the pixels whose primary ray ends on a sphere (include/skr.h skr_tile_costs)."""
+        n = (opt.height + tile_rows - 1) // tile_rows
+        out = np.zeros(n, np.uint32)
+        _check(lib().skr_tile_costs(self.h, C.byref(opt.c), tile_rows, out.ctypes.data), "skr_tile_costs")
+        return out
+
+    def shard_plan(self, opt, tile_rows, world):
+        """slot_of_tile of the map a frame step of `world` ranks uses (include/skr.h skr_shard_plan)."""
+        n = (opt.height + tile_rows - 1) // tile_rows
+        out = np.zeros(n, np.uint32)
+        _check(lib().skr_shard_plan(self.h, C.byref(opt.c), tile_rows, world, out.ctypes.data), "skr_shard_plan")
+        return out
+
     def render(self, opt, want_float=False, tile_rows=None, first_tile=0, tile_stride=1):
         """Render (a partition of) the frame into torch tensors on this device.  Returns
         (rgb uint8 [rows, W, 3], float32 image or None); rows are tile-major compact."""
@@ -349,6 +376,9 @@ class Renderer:
         out = (C.c_uint64 * 4)()
         _check(lib().skr_renderer_kernel_work(self.h, out), "skr_renderer_kernel_work")
         return {"radiance_rays": int(out[0]), "sphere_hits": int(out[1]), "shadow_rays": int(out[2]), "sphere_tests": int(out[3])}
+
+    def count_triangle_work(self, enable=True):
+        _check(lib().skr_renderer_count_triangle_work(self.h, int(enable)), "skr_renderer_count_triangle_work")
 
     def triangle_work(self, reset=True):
         """What the triangle walks executed (include/skr.h skr_renderer_read_triangle_work): call it BEFORE work(reset=True)."""
@@ -461,6 +491,17 @@ class Multi:
         _check(lib().skr_multi_render_frame_host(self.h, C.byref(opt.c), tile_rows, rgb.ctypes.data, C.byref(ms)), "skr_multi_render_frame_host")
         return rgb, ms.value
 
+    def render_frame_async(self, opt, tile_rows=8, want_previous=True):
+        """skr_multi_render_frame_async: returns the device address of the PREVIOUS call's frame (0 on the first call)."""
+        prev = C.c_void_p()
+        _check(lib().skr_multi_render_frame_async(self.h, C.byref(opt.c), tile_rows, C.byref(prev) if want_previous else None), "skr_multi_render_frame_async")
+        return prev.value or 0
+
+    def flush(self):
+        last = C.c_void_p()
+        _check(lib().skr_multi_flush(self.h, C.byref(last)), "skr_multi_flush")
+        return last.value or 0
+
     def counters(self, reset=True):
         tot = {"radiance_rays": 0, "sphere_hits": 0, "shadow_rays": 0}
         for i in range(self.n):
@@ -473,6 +514,22 @@ class Multi:
 
 def shard_tiles_per_rank(height, tile_rows, world):
     return int(lib().skr_shard_tiles_per_rank(height, tile_rows, world))
+
+
+def shard_lpt(cost, world):
+    """The cost-aware map: slot_of_tile[t] = rank * k_max + slot (include/skr.h skr_shard_lpt)."""
+    c = np.ascontiguousarray(cost, np.uint64)
+    out = np.zeros(len(c), np.uint32)
+    _check(lib().skr_shard_lpt(c.ctypes.data, len(c), world, out.ctypes.data), "skr_shard_lpt")
+    return out
+
+
+def shard_deinterleave_map_host(gathered, width, height, tile_rows, slot_of_tile):
+    g = np.ascontiguousarray(gathered, np.uint8)
+    m = np.ascontiguousarray(slot_of_tile, np.uint32)
+    out = np.zeros((height, width, 3), np.uint8)
+    _check(lib().skr_shard_deinterleave_map_host(g.ctypes.data, out.ctypes.data, width, height, tile_rows, m.ctypes.data), "skr_shard_deinterleave_map_host")
+    return out
 
 
 def shard_deinterleave_host(gathered, width, height, tile_rows, world):

@@ -18,15 +18,15 @@ __global__ __launch_bounds__(256) void skr_accumulate_kernel(float *__restrict__
 
 // mean = acc / passes; rows of a final partial tile beyond the image are left untouched, as skr_render_tiles leaves them
 __global__ __launch_bounds__(256) void skr_resolve_accumulated_kernel(const float *__restrict__ acc, float passes, uint32_t width, uint32_t out_rows, uint32_t height,
-																	  uint32_t tile_rows, uint32_t first_tile, uint32_t tile_stride, uint8_t *__restrict__ rgb, float *__restrict__ rgbf)
+																	  uint32_t tile_rows, uint32_t first_tile, uint32_t tile_stride, const uint32_t *__restrict__ tile_table, uint8_t *__restrict__ rgb, float *__restrict__ rgbf)
 {
 	const size_t n = (size_t) width * out_rows * 3, stride = (size_t) gridDim.x * blockDim.x;
 	for(size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
 	{
 		const uint32_t orow = (uint32_t) (i / ((size_t) width * 3));
 		const uint32_t k = orow / tile_rows;
-		const uint32_t y = (first_tile + k * tile_stride) * tile_rows + (orow - k * tile_rows);
-		if(y >= height) continue;
+		const uint32_t t = tile_table ? tile_table[k] : first_tile + k * tile_stride;
+		if(t == 0xFFFFFFFFu || t * tile_rows + (orow - k * tile_rows) >= height) continue;
 		const float m = sk_divf(acc[i], passes);
 		if(rgbf) rgbf[i] = m;
 		if(rgb) rgb[i] = (uint8_t) quantise(m);
@@ -47,11 +47,11 @@ hipError_t skr_launch_accumulate(float *acc, const float *frame, size_t n, int f
 }
 
 hipError_t skr_launch_resolve_accumulated(const float *acc, uint32_t passes, uint32_t width, uint32_t out_rows, uint32_t height, uint32_t tile_rows,
-										  uint32_t first_tile, uint32_t tile_stride, uint8_t *rgb, float *rgbf, hipStream_t stream)
+										  uint32_t first_tile, uint32_t tile_stride, const uint32_t *tile_table, uint8_t *rgb, float *rgbf, hipStream_t stream)
 {
 	const size_t n = (size_t) width * out_rows * 3;
 	if(n == 0) return hipSuccess;
 	hipLaunchKernelGGL(skr_resolve_accumulated_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, acc, (float) passes, width, out_rows, height, tile_rows, first_tile,
-					   tile_stride, rgb, rgbf);
+					   tile_stride, tile_table, rgb, rgbf);
 	return hipGetLastError();
 }

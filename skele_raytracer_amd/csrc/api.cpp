@@ -17,13 +17,14 @@ hipError_t skr_launch_debug(int op, const void *d_in, void *d_out, uint32_t n, h
 // accumulate.hip
 hipError_t skr_launch_accumulate(float *acc, const float *frame, size_t n, int first, hipStream_t stream);
 hipError_t skr_launch_resolve_accumulated(const float *acc, uint32_t passes, uint32_t width, uint32_t out_rows, uint32_t height, uint32_t tile_rows,
-										  uint32_t first_tile, uint32_t tile_stride, uint8_t *rgb, float *rgbf, hipStream_t stream);
+										  uint32_t first_tile, uint32_t tile_stride, const uint32_t *tile_table, uint8_t *rgb, float *rgbf, hipStream_t stream);
+hipError_t skr_launch_tile_costs(const RenderParams &p, uint32_t *d_hits, hipStream_t stream); // render_wave.hip
 size_t skr_render_lds_bytes(const RenderParams &p);
-bool skr_queue_selected(const RenderParams &p);
-void skr_queue_scratch_bytes(const RenderParams &p, size_t *parent_bytes, size_t *acc_bytes);
-bool skr_levels_scratch_bytes(RenderParams &p, size_t *p1_bytes, size_t *slot1_bytes);
 bool skr_nodes_selected(const RenderParams &p);
 size_t skr_nodes_scratch_bytes(const RenderParams &p);
+bool skr_generic_selected(const RenderParams &p);   // render_kernel.hip
+bool skr_generic_supported(const RenderParams &p);  // render_generic.hip
+size_t skr_generic_scratch_bytes(const RenderParams &p);
 bool skr_nodes_counter_layout(const RenderParams &p, size_t *off_ctr, size_t *level_words, int *levels);
 
 static thread_local const char *g_variant = "none";
@@ -51,13 +52,9 @@ struct skr_renderer {
 	unsigned long long *d_tri_work = nullptr; // 256 x {culling-sphere tests, triangle tests} executed by the triangle walks (skr_renderer_read_triangle_work)
 	int lds_limit = 0;
 	int pow_steps = 11; // bit length of the largest integer phong exponent in [1, 1024] among the scene's materials (device_math.h powf_spec)
-	// scratch of the parent-queue pipeline, grown on demand and kept
-	void *d_parents = nullptr;
-	void *d_levels = nullptr; // level-queue pipeline: level-1 hit records + level-1 slots
-	size_t levels_cap = 0;
+	// scratch, grown on demand and kept
 	void *d_nodes = nullptr;  // node pipeline: every table of one band (render_nodes.hip NodePlan)
 	size_t nodes_cap = 0;
-	size_t parents_cap = 0;
 	float *d_acc = nullptr;
 	size_t acc_cap = 0;
 	float *d_prog = nullptr; // progressive accumulation: this pass's float frame | the running sum
@@ -70,6 +67,7 @@ struct skr_renderer {
 	RenderParams last_p{}; // the launch last enqueued (skr_renderer_last_*_count)
 	bool last_nodes = false;
 	bool timing = false;
+	bool count_tri = false; // skr_renderer_count_triangle_work
 	std::vector<SkrTimingHook> timed;
 	std::vector<SkrTimingHook> free_pairs;
 };
@@ -78,10 +76,7 @@ static void load_switches(SkrSwitches &sw)
 {
 	sw = SkrSwitches();
 	if(const char *e = getenv("SKR_PIPELINE"))
-		sw.pipeline = !strcmp(e, "nodes") ? SKR_PIPE_NODES : !strcmp(e, "levels") ? SKR_PIPE_LEVELS : !strcmp(e, "queue") ? SKR_PIPE_QUEUE : !strcmp(e, "mega") ? SKR_PIPE_MEGA : SKR_PIPE_OTHER;
-	if(const char *e = getenv("SKR_KERNEL")) sw.kernel_v1 = !strcmp(e, "v1");
-	if(const char *e = getenv("SKR_OCC")) sw.occ = atoi(e) >= 3 ? 3 : 2;
-	if(const char *e = getenv("SKR_TILE")) sw.tile = (atoi(e) == 64 || atoi(e) == 32 || atoi(e) == 16) ? atoi(e) : 0;
+		sw.pipeline = !strcmp(e, "nodes") ? SKR_PIPE_NODES : !strcmp(e, "generic") ? SKR_PIPE_GENERIC : SKR_PIPE_OTHER;
 	sw.no_cones = getenv("SKR_NO_CONES") != nullptr;
 	sw.no_cull = getenv("SKR_NO_CULL") != nullptr;
 	if(const char *e = getenv("SKR_LEVELS_BUDGET_MB")) sw.budget_mb = atoi(e) > 0 ? atoi(e) : 1;
@@ -187,8 +182,6 @@ void skr_renderer_destroy(skr_renderer *r)
 	if(r->d_counters) (void) hipFree(r->d_counters);
 	if(r->d_tri_work) (void) hipFree(r->d_tri_work);
 	if(r->d_snap) (void) hipFree(r->d_snap);
-	if(r->d_parents) (void) hipFree(r->d_parents);
-	if(r->d_levels) (void) hipFree(r->d_levels);
 	if(r->d_nodes) (void) hipFree(r->d_nodes);
 	if(r->d_acc) (void) hipFree(r->d_acc);
 	if(r->d_prog) (void) hipFree(r->d_prog);
@@ -229,9 +222,22 @@ static int check_options(const skr_options *opt)
 }
 
 // one frame (one pass of a progressive render) of the tiles first_tile, first_tile + tile_stride, ...
-static int render_pass(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t first_tile, uint32_t tile_stride,
-					   uint32_t max_tiles, uint8_t *d_rgb, float *d_rgbf, void *stream)
+// the tiles of a launch: first, first + stride, ... (table == nullptr) or the n_slots entries of a device table (skr_render_tile_list)
+struct TileSel {
+	uint32_t first = 0, stride = 1, max_tiles = 0xffffffffu;
+	const uint32_t *d_table = nullptr;
+	uint32_t n_slots = 0;
+};
+static uint32_t sel_tiles(const skr_options *opt, uint32_t tile_rows, const TileSel &ts)
 {
+	if(ts.d_table) return ts.n_slots;
+	const uint32_t n = skr_tile_count(opt, tile_rows, ts.first, ts.stride);
+	return n > ts.max_tiles ? ts.max_tiles : n;
+}
+
+static int render_pass(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, const TileSel &ts, uint8_t *d_rgb, float *d_rgbf, void *stream)
+{
+	const uint32_t first_tile = ts.first, tile_stride = ts.stride;
 	if(!r || !opt || (!d_rgb && !d_rgbf) || tile_rows == 0 || tile_stride == 0)
 	{
 		skr_set_error("skr_render_tiles: bad argument");
@@ -239,8 +245,7 @@ static int render_pass(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	}
 	int rc = check_options(opt);
 	if(rc != SKR_OK) return rc;
-	uint32_t n_tiles = skr_tile_count(opt, tile_rows, first_tile, tile_stride);
-	if(n_tiles > max_tiles) n_tiles = max_tiles;
+	const uint32_t n_tiles = sel_tiles(opt, tile_rows, ts);
 	if(n_tiles == 0) return SKR_OK;
 	SKR_HIP(hipSetDevice(r->device));
 
@@ -250,6 +255,7 @@ static int render_pass(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.height = opt->height;
 	p.tile_rows = tile_rows;
 	p.first_tile = first_tile;
+	p.tile_table = ts.d_table;
 	p.tile_stride = tile_stride;
 	p.out_rows = n_tiles * tile_rows;
 	p.band_row0 = 0;
@@ -300,22 +306,7 @@ static int render_pass(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.shade_triangles = (opt->shade_triangles && p.n_tris > 0) ? 1 : 0;
 	p.tri_mats = r->d_blob + r->off_tri_mats;
 	p.legacy_reflect = (opt->legacy_reflect && p.n_spheres > 0) ? 1 : 0; // (only a sphere hit has the terms of raytrace.h:45-103)
-	if(p.legacy_reflect && p.shade_triangles)
-	{
-		skr_set_error("--legacy-reflect and --shade-triangles are separate modes of the lane-per-pixel kernel: choose one");
-		return SKR_ERR_UNSUPPORTED;
-	}
 	if(!p.legacy_reflect && (!p.monte_carlo || (p.n_spheres == 0 && !p.shade_triangles) || p.num_path_traces == 0)) p.max_depth = 1;
-	if(p.shade_triangles || p.legacy_reflect)
-	{ // only the lane-per-pixel kernel has these modes (include/skr.h skr_options.shade_triangles, .legacy_reflect)
-		p.sw.pipeline = SKR_PIPE_MEGA;
-		p.sw.kernel_v1 = 1;
-		if(p.max_depth > 6)
-		{
-			skr_set_error("%s renders --depth <= 6 (asked for %d)", p.shade_triangles ? "--shade-triangles" : "--legacy-reflect", p.max_depth);
-			return SKR_ERR_UNSUPPORTED;
-		}
-	}
 	if(p.max_depth > 1)
 	{ // tree node ids are 32-bit RNG counter words: need N^(depth-1) < 2^32
 		double nodes = 1;
@@ -332,17 +323,18 @@ static int render_pass(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.rgb = d_rgb;
 	p.rgbf = d_rgbf;
 	p.counters = r->d_counters;
-	p.tri_work = r->d_tri_work;
+	p.tri_work = r->count_tri ? r->d_tri_work : nullptr;
 	p.qctr = reinterpret_cast<uint32_t *>(r->d_counters + (size_t) SKR_COUNTER_SHARDS * 4 + 8);
-	const bool nodes_path = skr_nodes_selected(p);
-	if(!nodes_path && p.max_depth > 6)
+	const bool generic_path = skr_generic_selected(p);
+	const bool nodes_path = !generic_path && skr_nodes_selected(p);
+	if(generic_path && !skr_generic_supported(p))
 	{
-		skr_set_error("--depth %d with --gillum %d: the tables of one 16x16 pixel block exceed the scratch budget (SKR_LEVELS_BUDGET_MB)", p.max_depth, p.num_path_traces);
+		skr_set_error("--depth %d with %d children per node: the tables of one output row exceed the scratch budget (SKR_LEVELS_BUDGET_MB)", p.max_depth, p.num_path_traces + (p.legacy_reflect ? 2 * p.n_lights : 0));
 		return SKR_ERR_UNSUPPORTED;
 	}
-	if(nodes_path)
+	if(nodes_path || generic_path)
 	{
-		const size_t need = skr_nodes_scratch_bytes(p);
+		const size_t need = nodes_path ? skr_nodes_scratch_bytes(p) : skr_generic_scratch_bytes(p);
 		if(need > r->nodes_cap)
 		{
 			if(r->d_nodes) SKR_HIP(hipFree(r->d_nodes));
@@ -364,44 +356,6 @@ static int render_pass(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 				r->acc_cap = need_acc;
 			}
 			p.acc = r->d_acc;
-		}
-	}
-	else if(skr_queue_selected(p))
-	{ // grow the pipeline's scratch if this launch needs more (first call / larger frame only)
-		size_t need_par = 0, need_acc = 0;
-		skr_queue_scratch_bytes(p, &need_par, &need_acc);
-		if(need_par > r->parents_cap)
-		{
-			if(r->d_parents) SKR_HIP(hipFree(r->d_parents));
-			r->d_parents = nullptr;
-			r->parents_cap = 0;
-			SKR_HIP(hipMalloc(&r->d_parents, need_par));
-			r->parents_cap = need_par;
-		}
-		if(need_acc > r->acc_cap)
-		{
-			if(r->d_acc) SKR_HIP(hipFree(r->d_acc));
-			r->d_acc = nullptr;
-			r->acc_cap = 0;
-			SKR_HIP(hipMalloc((void **) &r->d_acc, need_acc));
-			r->acc_cap = need_acc;
-		}
-		p.parents = reinterpret_cast<float4 *>(r->d_parents);
-		p.slot0_scratch = reinterpret_cast<float *>(reinterpret_cast<char *>(r->d_parents) + (size_t) p.width * p.out_rows * 64);
-		p.acc = r->d_acc;
-		size_t need_p1 = 0, need_slot1 = 0;
-		if(skr_levels_scratch_bytes(p, &need_p1, &need_slot1))
-		{
-			if(need_p1 + need_slot1 > r->levels_cap)
-			{
-				if(r->d_levels) SKR_HIP(hipFree(r->d_levels));
-				r->d_levels = nullptr;
-				r->levels_cap = 0;
-				SKR_HIP(hipMalloc(&r->d_levels, need_p1 + need_slot1));
-				r->levels_cap = need_p1 + need_slot1;
-			}
-			p.p1 = reinterpret_cast<float4 *>(r->d_levels);
-			p.slot1 = reinterpret_cast<float *>(reinterpret_cast<char *>(r->d_levels) + need_p1);
 		}
 	}
 	if(skr_render_lds_bytes(p) > (size_t) r->lds_limit)
@@ -454,19 +408,17 @@ static int ensure_progressive_scratch(skr_renderer *r, size_t n)
 
 // skr_options.progressive_passes: K frames under the seeds s, s+1, ..., s+K-1, summed in binary32 in pass
 // order, divided by K once and quantised like a single frame (accumulate.hip).  K <= 1 is the single frame itself.
-static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t first_tile, uint32_t tile_stride,
-					   uint32_t max_tiles, uint8_t *d_rgb, float *d_rgbf, void *stream)
+static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, const TileSel &ts, uint8_t *d_rgb, float *d_rgbf, void *stream)
 {
-	if(!opt || opt->progressive_passes <= 1) return render_pass(r, opt, tile_rows, first_tile, tile_stride, max_tiles, d_rgb, d_rgbf, stream);
-	if(!r || (!d_rgb && !d_rgbf) || tile_rows == 0 || tile_stride == 0)
+	if(!opt || opt->progressive_passes <= 1) return render_pass(r, opt, tile_rows, ts, d_rgb, d_rgbf, stream);
+	if(!r || (!d_rgb && !d_rgbf) || tile_rows == 0 || ts.stride == 0)
 	{
 		skr_set_error("skr_render_tiles: bad argument");
 		return SKR_ERR_ARG;
 	}
 	int rc = check_options(opt);
 	if(rc != SKR_OK) return rc;
-	uint32_t n_tiles = skr_tile_count(opt, tile_rows, first_tile, tile_stride);
-	if(n_tiles > max_tiles) n_tiles = max_tiles;
+	const uint32_t n_tiles = sel_tiles(opt, tile_rows, ts);
 	if(n_tiles == 0) return SKR_OK;
 	SKR_HIP(hipSetDevice(r->device));
 	const uint32_t out_rows = n_tiles * tile_rows;
@@ -479,19 +431,83 @@ static int render_impl(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	for(int32_t k = 0; k < opt->progressive_passes; k++)
 	{
 		pass.seed = opt->seed + (uint64_t) k;
-		rc = render_pass(r, &pass, tile_rows, first_tile, tile_stride, max_tiles, nullptr, frame, stream);
+		rc = render_pass(r, &pass, tile_rows, ts, nullptr, frame, stream);
 		if(rc != SKR_OK) return rc;
 		SKR_HIP(skr_launch_accumulate(acc, frame, n, k == 0, (hipStream_t) stream));
 	}
-	SKR_HIP(skr_launch_resolve_accumulated(acc, (uint32_t) opt->progressive_passes, (uint32_t) opt->width, out_rows, (uint32_t) opt->height, tile_rows, first_tile,
-										   tile_stride, d_rgb, d_rgbf, (hipStream_t) stream));
+	SKR_HIP(skr_launch_resolve_accumulated(acc, (uint32_t) opt->progressive_passes, (uint32_t) opt->width, out_rows, (uint32_t) opt->height, tile_rows, ts.first,
+										   ts.stride, ts.d_table, d_rgb, d_rgbf, (hipStream_t) stream));
 	return SKR_OK;
 }
 
 int skr_render_tiles(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t first_tile, uint32_t tile_stride,
 					 uint8_t *d_rgb, float *d_rgbf, void *stream)
 {
-	return render_impl(r, opt, tile_rows, first_tile, tile_stride, 0xffffffffu, d_rgb, d_rgbf, stream);
+	TileSel ts;
+	ts.first = first_tile;
+	ts.stride = tile_stride;
+	return render_impl(r, opt, tile_rows, ts, d_rgb, d_rgbf, stream);
+}
+
+int skr_render_tile_list(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, const uint32_t *d_tiles, uint32_t n_slots, uint8_t *d_rgb, float *d_rgbf, void *stream)
+{
+	if(!d_tiles)
+	{
+		skr_set_error("skr_render_tile_list: no tile table");
+		return SKR_ERR_ARG;
+	}
+	TileSel ts;
+	ts.d_table = d_tiles;
+	ts.n_slots = n_slots;
+	return render_impl(r, opt, tile_rows, ts, d_rgb, d_rgbf, stream);
+}
+
+// Per tile of `tile_rows` image rows: the number of its pixels whose primary ray ends on a sphere — the pixels under which the
+// --gillum tree grows, i.e. what a tile costs beyond its primary rays.  Synchronous; h_hits has ceil(height / tile_rows) entries.
+int skr_tile_costs(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t *h_hits)
+{
+	if(!r || !opt || !h_hits || tile_rows == 0) return SKR_ERR_ARG;
+	int rc = check_options(opt);
+	if(rc != SKR_OK) return rc;
+	SKR_HIP(hipSetDevice(r->device));
+	const uint32_t T = ((uint32_t) opt->height + tile_rows - 1) / tile_rows;
+	RenderParams p{};
+	p.width = opt->width;
+	p.height = opt->height;
+	p.tile_rows = tile_rows;
+	p.first_tile = 0;
+	p.tile_stride = 1;
+	p.out_rows = T * tile_rows;
+	p.inv_width = 1 / float(opt->width);
+	p.inv_height = 1 / float(opt->height);
+	p.aspect = opt->width / float(opt->height);
+	p.angle = (float) tan(M_PI * 0.5 * opt->fov / 180.);
+	const float *c = r->info.camera;
+	p.cam_pos = f3{c[0], c[1], c[2]};
+	p.cam_dir = f3{c[3], c[4], c[5]};
+	p.cam_up = f3{c[6], c[7], c[8]};
+	p.cam_right = f3{c[9], c[10], c[11]};
+	p.n_spheres = r->info.n_spheres;
+	p.n_lights = 0;
+	p.n_tris = 0; // (a triangle in front of a sphere makes the estimate a little high: it is only an estimate)
+	p.sph_geom = r->d_blob;
+	p.sph_amb = r->d_blob + r->off_amb;
+	p.sph_kd = r->d_blob + r->off_kd;
+	p.sph_ks = r->d_blob + r->off_ks;
+	p.lights = r->d_blob + r->off_lights;
+	p.grid_size = 0; // (pixel centres)
+	uint32_t *d_hits = nullptr;
+	SKR_HIP(hipMalloc((void **) &d_hits, (size_t) T * sizeof(uint32_t)));
+	hipError_t e = hipMemset(d_hits, 0, (size_t) T * sizeof(uint32_t));
+	if(e == hipSuccess) e = skr_launch_tile_costs(p, d_hits, nullptr);
+	if(e == hipSuccess) e = hipMemcpy(h_hits, d_hits, (size_t) T * sizeof(uint32_t), hipMemcpyDeviceToHost);
+	(void) hipFree(d_hits);
+	if(e != hipSuccess)
+	{
+		skr_set_error("skr_tile_costs: %s", hipGetErrorString(e));
+		return SKR_ERR_HIP;
+	}
+	return SKR_OK;
 }
 
 int skr_accumulate(float *d_acc, const float *d_frame, uint64_t n_floats, int first, void *stream)
@@ -512,7 +528,7 @@ int skr_resolve_accumulated(const float *d_acc, uint32_t passes, uint32_t width,
 		skr_set_error("skr_resolve_accumulated: bad argument");
 		return SKR_ERR_ARG;
 	}
-	SKR_HIP(skr_launch_resolve_accumulated(d_acc, passes, width, height, height, height ? height : 1, 0, 1, d_rgb, d_rgbf, (hipStream_t) stream));
+	SKR_HIP(skr_launch_resolve_accumulated(d_acc, passes, width, height, height, height ? height : 1, 0, 1, nullptr, d_rgb, d_rgbf, (hipStream_t) stream));
 	return SKR_OK;
 }
 
@@ -531,7 +547,11 @@ int skr_render_rows(skr_renderer *r, const skr_options *opt, uint32_t y0, uint32
 		a = b;
 		b = t;
 	}
-	return render_impl(r, opt, a, y0 / a, 1, (y1 - y0) / a, d_rgb, d_rgbf, stream);
+	TileSel ts;
+	ts.first = y0 / a;
+	ts.stride = 1;
+	ts.max_tiles = (y1 - y0) / a;
+	return render_impl(r, opt, a, ts, d_rgb, d_rgbf, stream);
 }
 
 int skr_renderer_reload_switches(skr_renderer *r)
@@ -594,8 +614,8 @@ int skr_renderer_last_parent_count(skr_renderer *r, uint32_t *n)
 {
 	if(!r || !n) return SKR_ERR_ARG;
 	SKR_HIP(hipSetDevice(r->device));
-	if(r->last_nodes) return nodes_level_count(r, 0, n);
-	SKR_HIP(hipMemcpy(n, r->d_counters + (size_t) SKR_COUNTER_SHARDS * 4 + 8, sizeof(uint32_t), hipMemcpyDeviceToHost));
+	*n = 0;
+	if(r->last_nodes) return nodes_level_count(r, 0, n); // (only the node pipeline has level tables of this layout)
 	return SKR_OK;
 }
 
@@ -603,12 +623,8 @@ int skr_renderer_last_level1_count(skr_renderer *r, uint32_t *n)
 {
 	if(!r || !n) return SKR_ERR_ARG;
 	SKR_HIP(hipSetDevice(r->device));
+	*n = 0;
 	if(r->last_nodes) return nodes_level_count(r, 1, n);
-	std::vector<uint32_t> h((size_t) (SKR_PULL_QUEUES + 1 + SKR_P1_REGIONS) * SKR_PULL_STRIDE);
-	SKR_HIP(hipMemcpy(h.data(), r->d_counters + (size_t) SKR_COUNTER_SHARDS * 4 + 8, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-	uint64_t total = 0;
-	for(uint32_t k = 0; k < SKR_P1_REGIONS; k++) total += h[(size_t) SKR_PULL_STRIDE * (1u + SKR_PULL_QUEUES + k)];
-	*n = (uint32_t) total;
 	return SKR_OK;
 }
 
@@ -639,6 +655,13 @@ int skr_renderer_read_work(skr_renderer *r, uint64_t out[4], int reset)
 	if(rc != SKR_OK) return rc;
 	// every radiance ray tests every sphere (raytrace.h:152-165); a shadow ray stops at its first occluder (utils.h:52-55)
 	out[3] += out[0] * (uint64_t) r->info.n_spheres;
+	return SKR_OK;
+}
+
+int skr_renderer_count_triangle_work(skr_renderer *r, int enable)
+{
+	if(!r) return SKR_ERR_ARG;
+	r->count_tri = enable != 0;
 	return SKR_OK;
 }
 
@@ -728,11 +751,11 @@ int skr_render_progressive_host(skr_renderer *r, const skr_options *opt, uint32_
 	{
 		pass.seed = opt->seed + (uint64_t) k;
 		SKR_HIP(hipEventRecord(r->frame_e0, nullptr));
-		rc = render_pass(r, &pass, (uint32_t) opt->height, 0, 1, 0xffffffffu, nullptr, frame, nullptr);
+		rc = render_pass(r, &pass, (uint32_t) opt->height, TileSel(), nullptr, frame, nullptr);
 		if(rc != SKR_OK) return rc;
 		SKR_HIP(skr_launch_accumulate(acc, frame, n, k == 0, nullptr));
 		const bool show = (k + 1) % every == 0 || k + 1 == passes;
-		if(show) SKR_HIP(skr_launch_resolve_accumulated(acc, k + 1, (uint32_t) opt->width, (uint32_t) opt->height, (uint32_t) opt->height, (uint32_t) opt->height, 0, 1, d_rgb, d_rgbf, nullptr));
+		if(show) SKR_HIP(skr_launch_resolve_accumulated(acc, k + 1, (uint32_t) opt->width, (uint32_t) opt->height, (uint32_t) opt->height, (uint32_t) opt->height, 0, 1, nullptr, d_rgb, d_rgbf, nullptr));
 		SKR_HIP(hipEventRecord(r->frame_e1, nullptr));
 		if(show)
 		{

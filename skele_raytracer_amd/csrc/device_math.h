@@ -540,7 +540,7 @@ SKR_DEV bool triangle_hit(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float &t)
 	const f3 p = cross3(d, e2);
 	const float det = dot3(e1, p);
 	if(fabsf(det) < 0.00001f) return false;
-	const float inv = sk_rcpf(det);
+	const float inv = sk_divf(1.0f, det); // (the compiler's expansion: in this divergent inner loop the short form's range branch cost the dragon walk 20 %)
 	const f3 tv = o - v0;
 	const float u = inv * dot3(mk3(-tv.x, -tv.y, -tv.z), p);
 	if(u < 0 || u > 1) return false;

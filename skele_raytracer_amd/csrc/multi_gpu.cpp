@@ -18,6 +18,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
@@ -95,19 +96,71 @@ Rccl &rccl()
 uint32_t tiles_total(int32_t height, uint32_t tile_rows) { return ((uint32_t) height + tile_rows - 1) / tile_rows; }
 uint32_t tiles_per_rank(int32_t height, uint32_t tile_rows, uint32_t world) { return (tiles_total(height, tile_rows) + world - 1) / world; }
 
-// gathered: [world][k_max * tile_rows][row_bytes] (rank-major, what the all-gather leaves) -> frame[height][row_bytes].
-// Tile t lives at rank t mod world, slot t / world.  One 16-byte word per thread where the rows allow it.
+// The tile -> (rank, slot) map.  Tiles differ in cost by an order of magnitude (sky rows: one ray per pixel; ground rows: a tree of up
+// to 1 + N + N^2 rays under every pixel), and dealing them out blindly (tile t to rank t mod G, rounds 1-2) left the slowest of 8
+// ranks 30 % above the mean.  Here every tile has a cost estimate — its pixels plus, for every pixel whose primary ray ends on a
+// sphere (counted by skr_tile_costs: a 0.1 ms kernel, once per frame geometry), the tree under it — and the tiles are dealt by
+// longest-processing-time-first: most expensive tile first, each to the rank with the least work so far that still has a free slot
+// (every rank has k_max = ceil(T / G) slots: the all-gather moves equal chunks).  Deterministic — integer counts, a stable sort,
+// ties to the lower index — so every rank of a job computes the same map without talking to the others.
+// slot_of_tile[t] = rank * k_max + k.  The image cannot change with the map: the RNG is keyed by the global pixel.
+void shard_interleaved(uint32_t T, uint32_t world, uint32_t *slot_of_tile)
+{
+	const uint32_t k_max = (T + world - 1) / world;
+	for(uint32_t t = 0; t < T; t++) slot_of_tile[t] = (t % world) * k_max + t / world;
+}
+
+void shard_lpt(const uint64_t *cost, uint32_t T, uint32_t world, uint32_t *slot_of_tile)
+{
+	const uint32_t k_max = (T + world - 1) / world;
+	std::vector<uint32_t> order(T);
+	for(uint32_t t = 0; t < T; t++) order[t] = t;
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+	std::vector<uint64_t> load(world, 0);
+	std::vector<uint32_t> used(world, 0);
+	for(uint32_t i = 0; i < T; i++)
+	{
+		const uint32_t t = order[i];
+		uint32_t best = world;
+		for(uint32_t r = 0; r < world; r++)
+			if(used[r] < k_max && (best == world || load[r] < load[best])) best = r;
+		slot_of_tile[t] = best * k_max + used[best];
+		used[best]++;
+		load[best] += cost[t];
+	}
+}
+
+// what a tile costs, in primary-ray units: its pixels, plus for every pixel with a sphere under it the rays of the tree below
+// (a child ray hits a sphere about one time in three in the reference's scenes; a shaded hit costs about two more rays' worth)
+void tile_costs_from_hits(const skr_options *opt, uint32_t tile_rows, const uint32_t *hits, uint32_t T, uint64_t *cost)
+{
+	double tree = 0, level = 1;
+	if(opt->monte_carlo && opt->num_path_traces > 0)
+		for(int k = 1; k < opt->max_depth && k < 8; k++)
+		{
+			level *= (double) opt->num_path_traces * (k == 1 ? 1.0 : 0.33);
+			tree += level;
+		}
+	for(uint32_t t = 0; t < T; t++)
+	{
+		const uint32_t rows = (t + 1) * tile_rows <= (uint32_t) opt->height ? tile_rows : (uint32_t) opt->height - t * tile_rows;
+		cost[t] = (uint64_t) rows * (uint64_t) opt->width + (uint64_t) ((double) hits[t] * (2.0 + tree));
+	}
+}
+
+// gathered: [world][k_max * tile_rows][row_bytes] (rank-major, what the all-gather leaves) -> frame[height][row_bytes]; row y of tile
+// t = y / tile_rows lives in slot slot_of_tile[t].  One 16-byte word per thread where the rows allow it.
 template <typename T>
-__global__ __launch_bounds__(256) void skr_deinterleave_kernel(const T *gathered, T *frame, uint32_t height, uint32_t row_words, uint32_t tile_rows, uint32_t world, uint32_t k_max)
+__global__ __launch_bounds__(256) void skr_deinterleave_kernel(const T *gathered, T *frame, uint32_t height, uint32_t row_words, uint32_t tile_rows, const uint32_t *slot_of_tile)
 {
 	const uint64_t i = (uint64_t) blockIdx.x * 256u + threadIdx.x;
 	if(i >= (uint64_t) height * row_words) return;
 	const uint32_t y = (uint32_t) (i / row_words), x = (uint32_t) (i - (uint64_t) y * row_words);
-	const uint32_t t = y / tile_rows, rank = t % world, k = t / world;
-	frame[i] = gathered[((uint64_t) rank * k_max * tile_rows + (uint64_t) k * tile_rows + (y - t * tile_rows)) * row_words + x];
+	const uint32_t t = y / tile_rows;
+	frame[i] = gathered[((uint64_t) slot_of_tile[t] * tile_rows + (y - t * tile_rows)) * row_words + x];
 }
 
-hipError_t launch_deinterleave(const uint8_t *gathered, uint8_t *frame, int32_t width, int32_t height, uint32_t tile_rows, uint32_t world, uint32_t k_max, hipStream_t stream)
+hipError_t launch_deinterleave(const uint8_t *gathered, uint8_t *frame, int32_t width, int32_t height, uint32_t tile_rows, const uint32_t *d_slot_of_tile, hipStream_t stream)
 {
 	const size_t row_bytes = (size_t) width * 3;
 	if(row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(gathered) | reinterpret_cast<uintptr_t>(frame)) % 16 == 0)
@@ -115,15 +168,85 @@ hipError_t launch_deinterleave(const uint8_t *gathered, uint8_t *frame, int32_t 
 		const uint32_t rw = (uint32_t) (row_bytes / 16);
 		const uint64_t n = (uint64_t) height * rw;
 		hipLaunchKernelGGL(skr_deinterleave_kernel<uint4>, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(gathered),
-						   reinterpret_cast<uint4 *>(frame), (uint32_t) height, rw, tile_rows, world, k_max);
+						   reinterpret_cast<uint4 *>(frame), (uint32_t) height, rw, tile_rows, d_slot_of_tile);
 	}
 	else
 	{
 		const uint64_t n = (uint64_t) height * row_bytes;
 		hipLaunchKernelGGL(skr_deinterleave_kernel<uint8_t>, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, gathered, frame, (uint32_t) height,
-						   (uint32_t) row_bytes, tile_rows, world, k_max);
+						   (uint32_t) row_bytes, tile_rows, d_slot_of_tile);
 	}
 	return hipGetLastError();
+}
+
+// The map of one frame geometry on one device: host copy, and on the device the rank's own tile list (what skr_render_tile_list
+// takes) and slot_of_tile (what the de-interleave takes).  Rebuilt when the geometry, the tree or the scene behind it changes.
+struct ShardMap {
+	const skr_renderer *r = nullptr;
+	int32_t width = 0, height = 0, monte_carlo = 0, gillum = 0, depth = 0;
+	float fov = 0;
+	uint32_t tile_rows = 0, world = 0, rank = 0, T = 0, k_max = 0;
+	std::vector<uint32_t> slot_of_tile;
+	uint32_t *d_tiles = nullptr;        // k_max entries: the tiles of `rank` in slot order (0xFFFFFFFF: an empty slot)
+	uint32_t *d_slot_of_tile = nullptr; // T entries
+};
+
+bool lpt_wanted()
+{ // SKR_SHARD=interleave: the blind map of rounds 1-2 (A/B runs, tests)
+	const char *e = getenv("SKR_SHARD");
+	return !(e && !strcmp(e, "interleave"));
+}
+
+void free_map(ShardMap &m)
+{
+	if(m.d_tiles) (void) hipFree(m.d_tiles);
+	if(m.d_slot_of_tile) (void) hipFree(m.d_slot_of_tile);
+	m = ShardMap();
+}
+
+// `shared`: a map already computed for this geometry on another device of the same process (skr_multi): only uploaded here
+int ensure_map(ShardMap &m, skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t world, uint32_t rank, const std::vector<uint32_t> *shared)
+{
+	const bool same = m.r == r && m.width == opt->width && m.height == opt->height && m.fov == opt->fov && m.tile_rows == tile_rows && m.world == world && m.rank == rank &&
+					  m.monte_carlo == opt->monte_carlo && m.gillum == opt->num_path_traces && m.depth == opt->max_depth && m.d_tiles;
+	if(same && !shared) return SKR_OK;
+	if(same && shared && *shared == m.slot_of_tile) return SKR_OK;
+	free_map(m);
+	m.r = r;
+	m.width = opt->width;
+	m.height = opt->height;
+	m.fov = opt->fov;
+	m.monte_carlo = opt->monte_carlo;
+	m.gillum = opt->num_path_traces;
+	m.depth = opt->max_depth;
+	m.tile_rows = tile_rows;
+	m.world = world;
+	m.rank = rank;
+	m.T = tiles_total(opt->height, tile_rows);
+	m.k_max = tiles_per_rank(opt->height, tile_rows, world);
+	if(shared) m.slot_of_tile = *shared;
+	else
+	{
+		m.slot_of_tile.assign(m.T, 0);
+		if(world > 1 && lpt_wanted())
+		{
+			std::vector<uint32_t> hits(m.T);
+			const int rc = skr_tile_costs(r, opt, tile_rows, hits.data());
+			if(rc != SKR_OK) return rc;
+			std::vector<uint64_t> cost(m.T);
+			tile_costs_from_hits(opt, tile_rows, hits.data(), m.T, cost.data());
+			shard_lpt(cost.data(), m.T, world, m.slot_of_tile.data());
+		}
+		else shard_interleaved(m.T, world, m.slot_of_tile.data());
+	}
+	std::vector<uint32_t> mine(m.k_max, 0xFFFFFFFFu);
+	for(uint32_t t = 0; t < m.T; t++)
+		if(m.slot_of_tile[t] / m.k_max == rank) mine[m.slot_of_tile[t] % m.k_max] = t;
+	SKR_HIP(hipMalloc((void **) &m.d_tiles, (size_t) m.k_max * sizeof(uint32_t)));
+	SKR_HIP(hipMalloc((void **) &m.d_slot_of_tile, (size_t) m.T * sizeof(uint32_t)));
+	SKR_HIP(hipMemcpy(m.d_tiles, mine.data(), (size_t) m.k_max * sizeof(uint32_t), hipMemcpyHostToDevice));
+	SKR_HIP(hipMemcpy(m.d_slot_of_tile, m.slot_of_tile.data(), (size_t) m.T * sizeof(uint32_t), hipMemcpyHostToDevice));
+	return SKR_OK;
 }
 
 // one rank's buffers for one frame geometry
@@ -180,6 +303,7 @@ struct skr_comm {
 	int device = 0, rank = 0, world = 1;
 	ncclComm_t comm = nullptr;
 	RankBuffers buf;
+	ShardMap map; // the tile -> rank map of the frame geometry last rendered
 	// pipelined frames (skr_comm_render_frame_async): two buffer sets, the collective on a stream of its own
 	RankBuffers abuf[2];
 	hipStream_t cs = nullptr;
@@ -249,6 +373,7 @@ void skr_comm_destroy(skr_comm *c)
 	(void) hipSetDevice(c->device);
 	if(c->cs) (void) hipStreamSynchronize(c->cs);
 	free_buffers(c->buf);
+	free_map(c->map);
 	for(int k = 0; k < 2; k++)
 	{
 		free_buffers(c->abuf[k]);
@@ -270,12 +395,14 @@ int skr_comm_render_frame(skr_comm *c, const skr_options *opt, uint32_t tile_row
 	SKR_HIP(hipSetDevice(c->device));
 	rc = size_buffers(c->buf, opt, tile_rows, (uint32_t) c->world, c->rank == 0);
 	if(rc != SKR_OK) return rc;
+	rc = ensure_map(c->map, c->r, opt, tile_rows, (uint32_t) c->world, (uint32_t) c->rank, nullptr);
+	if(rc != SKR_OK) return rc;
 	RankBuffers &b = c->buf;
 	uint8_t *mine = b.d_gather + (size_t) c->rank * b.chunk;
-	rc = skr_render_tiles(c->r, opt, tile_rows, (uint32_t) c->rank, (uint32_t) c->world, mine, nullptr, stream);
+	rc = skr_render_tile_list(c->r, opt, tile_rows, c->map.d_tiles, c->map.k_max, mine, nullptr, stream);
 	if(rc != SKR_OK) return rc;
 	if(c->comm) SKR_NCCL(rccl().AllGather(mine, b.d_gather, b.chunk, ncclUint8, c->comm, (hipStream_t) stream)); // in place: slot `rank` is the send buffer
-	if(c->rank == 0) SKR_HIP(launch_deinterleave(b.d_gather, b.d_frame, opt->width, opt->height, tile_rows, (uint32_t) c->world, b.k_max, (hipStream_t) stream));
+	if(c->rank == 0) SKR_HIP(launch_deinterleave(b.d_gather, b.d_frame, opt->width, opt->height, tile_rows, c->map.d_slot_of_tile, (hipStream_t) stream));
 	if(d_frame) *d_frame = c->rank == 0 ? b.d_frame : nullptr;
 	return SKR_OK;
 }
@@ -310,13 +437,18 @@ int skr_comm_render_frame_async(skr_comm *c, const skr_options *opt, uint32_t ti
 	}
 	rc = size_buffers(b, opt, tile_rows, (uint32_t) c->world, c->rank == 0);
 	if(rc != SKR_OK) return rc;
+	if(c->map.d_tiles && (c->map.width != opt->width || c->map.height != opt->height || c->map.tile_rows != tile_rows || c->map.fov != opt->fov ||
+						  c->map.gillum != opt->num_path_traces || c->map.depth != opt->max_depth || c->map.monte_carlo != opt->monte_carlo))
+		SKR_HIP(hipStreamSynchronize(c->cs)); // (a de-interleave in flight still reads the old map)
+	rc = ensure_map(c->map, c->r, opt, tile_rows, (uint32_t) c->world, (uint32_t) c->rank, nullptr);
+	if(rc != SKR_OK) return rc;
 	uint8_t *mine = b.d_gather + (size_t) c->rank * b.chunk;
-	rc = skr_render_tiles(c->r, opt, tile_rows, (uint32_t) c->rank, (uint32_t) c->world, mine, nullptr, stream);
+	rc = skr_render_tile_list(c->r, opt, tile_rows, c->map.d_tiles, c->map.k_max, mine, nullptr, stream);
 	if(rc != SKR_OK) return rc;
 	SKR_HIP(hipEventRecord(c->rendered[s], rs));
 	SKR_HIP(hipStreamWaitEvent(c->cs, c->rendered[s], 0));
 	if(c->comm) SKR_NCCL(rccl().AllGather(mine, b.d_gather, b.chunk, ncclUint8, c->comm, c->cs));
-	if(c->rank == 0) SKR_HIP(launch_deinterleave(b.d_gather, b.d_frame, opt->width, opt->height, tile_rows, (uint32_t) c->world, b.k_max, c->cs));
+	if(c->rank == 0) SKR_HIP(launch_deinterleave(b.d_gather, b.d_frame, opt->width, opt->height, tile_rows, c->map.d_slot_of_tile, c->cs));
 	SKR_HIP(hipEventRecord(c->gathered[s], c->cs));
 	c->in_flight[s] = true;
 	c->async_frames++;
@@ -372,6 +504,14 @@ struct skr_multi {
 	std::vector<hipStream_t> streams;
 	std::vector<ncclComm_t> comms;
 	std::vector<RankBuffers> bufs;
+	std::vector<ShardMap> maps; // the tile -> rank map, computed on device 0 and uploaded to every device
+	// pipelined frames (skr_multi_render_frame_async): two buffer sets per device, the collective on a stream of its own per device
+	std::vector<RankBuffers> abufs[2];
+	std::vector<hipStream_t> cstreams;
+	std::vector<hipEvent_t> rendered[2], gathered[2];
+	bool in_flight[2] = {false, false};
+	uint64_t async_frames = 0;
+	int async_set = -1; // >= 0: the workers render into abufs[async_set] (and order themselves behind its last collective)
 	hipEvent_t e0 = nullptr, e1 = nullptr; // root stream: frame time
 	// one worker thread per device (a single thread would enqueue 8 devices' launch sequences one after the other)
 	std::vector<std::thread> workers;
@@ -392,11 +532,74 @@ namespace {
 int multi_render_rank(skr_multi *m, int i)
 {
 	SKR_HIP(hipSetDevice(m->devices[i]));
-	int rc = size_buffers(m->bufs[i], m->opt, m->tile_rows, (uint32_t) m->n, i == 0);
+	const int set = m->async_set;
+	RankBuffers &b = set >= 0 ? m->abufs[set][i] : m->bufs[i];
+	if(set >= 0 && m->in_flight[set]) SKR_HIP(hipStreamWaitEvent(m->streams[i], m->gathered[set][i], 0)); // the collective of frame f - 2 read these buffers
+	int rc = size_buffers(b, m->opt, m->tile_rows, (uint32_t) m->n, i == 0);
 	if(rc != SKR_OK) return rc;
-	RankBuffers &b = m->bufs[i];
-	if(i == 0) SKR_HIP(hipEventRecord(m->e0, m->streams[0]));
-	return skr_render_tiles(m->renderers[i], m->opt, m->tile_rows, (uint32_t) i, (uint32_t) m->n, b.d_gather + (size_t) i * b.chunk, nullptr, m->streams[i]);
+	if(i != 0)
+	{ // (device 0's map was made by the caller before the workers were woken: here it is only uploaded)
+		rc = ensure_map(m->maps[i], m->renderers[i], m->opt, m->tile_rows, (uint32_t) m->n, (uint32_t) i, &m->maps[0].slot_of_tile);
+		if(rc != SKR_OK) return rc;
+	}
+	if(i == 0 && set < 0) SKR_HIP(hipEventRecord(m->e0, m->streams[0]));
+	rc = skr_render_tile_list(m->renderers[i], m->opt, m->tile_rows, m->maps[i].d_tiles, m->maps[i].k_max, b.d_gather + (size_t) i * b.chunk, nullptr, m->streams[i]);
+	if(rc != SKR_OK) return rc;
+	if(set >= 0) SKR_HIP(hipEventRecord(m->rendered[set][i], m->streams[i]));
+	return SKR_OK;
+}
+
+// every device renders its tiles of one frame (the calling thread drives device 0, the workers the others); returns when all are enqueued
+int multi_render_all(skr_multi *m, const skr_options *opt, uint32_t tile_rows)
+{
+	SKR_HIP(hipSetDevice(m->devices[0]));
+	int rc = ensure_map(m->maps[0], m->renderers[0], opt, tile_rows, (uint32_t) m->n, 0u, nullptr);
+	if(rc != SKR_OK) return rc;
+	{
+		std::lock_guard<std::mutex> lk(m->mu);
+		m->opt = opt;
+		m->tile_rows = tile_rows;
+		m->pending = m->n - 1;
+		m->generation++;
+	}
+	m->cv_go.notify_all();
+	m->status[0] = multi_render_rank(m, 0);
+	if(m->status[0] != SKR_OK) m->errors[0] = skr_last_error();
+	{
+		std::unique_lock<std::mutex> lk(m->mu);
+		m->cv_done.wait(lk, [&] { return m->pending == 0; });
+	}
+	for(int i = 0; i < m->n; i++)
+		if(m->status[i] != SKR_OK)
+		{
+			skr_set_error("device %d: %s", m->devices[i], m->errors[i].c_str());
+			return m->status[i];
+		}
+	return SKR_OK;
+}
+
+// one grouped all-gather of every device's chunk, each on the stream given for its device, then the root's de-interleave
+int multi_collect(skr_multi *m, std::vector<RankBuffers> &bufs, const std::vector<hipStream_t> &on, const skr_options *opt, uint32_t tile_rows)
+{
+	if(m->comms[0])
+	{
+		SKR_NCCL(rccl().GroupStart());
+		for(int i = 0; i < m->n; i++)
+		{
+			RankBuffers &b = bufs[i];
+			const ncclResult_t ne = rccl().AllGather(b.d_gather + (size_t) i * b.chunk, b.d_gather, b.chunk, ncclUint8, m->comms[i], on[i]);
+			if(ne != ncclSuccess)
+			{
+				(void) rccl().GroupEnd();
+				skr_set_error("ncclAllGather(rank %d) failed: %s", i, rccl().GetErrorString(ne));
+				return SKR_ERR_HIP;
+			}
+		}
+		SKR_NCCL(rccl().GroupEnd());
+	}
+	SKR_HIP(hipSetDevice(m->devices[0]));
+	SKR_HIP(launch_deinterleave(bufs[0].d_gather, bufs[0].d_frame, opt->width, opt->height, tile_rows, m->maps[0].d_slot_of_tile, on[0]));
+	return SKR_OK;
 }
 
 void worker_main(skr_multi *m, int i)
@@ -451,6 +654,7 @@ int skr_multi_create(const skr_scene *scene, int n_devices, const int *devices, 
 	m->streams.assign(n_devices, nullptr);
 	m->comms.assign(n_devices, nullptr);
 	m->bufs.resize(n_devices);
+	m->maps.resize(n_devices);
 	m->status.assign(n_devices, SKR_OK);
 	m->errors.resize(n_devices);
 	int rc = SKR_OK;
@@ -501,7 +705,16 @@ void skr_multi_destroy(skr_multi *m)
 	{
 		(void) hipSetDevice(m->devices[i]);
 		if(m->streams[i]) (void) hipStreamSynchronize(m->streams[i]);
+		if(i < (int) m->cstreams.size() && m->cstreams[i]) (void) hipStreamSynchronize(m->cstreams[i]);
 		free_buffers(m->bufs[i]);
+		if(i < (int) m->maps.size()) free_map(m->maps[i]);
+		for(int k = 0; k < 2; k++)
+		{
+			if(i < (int) m->abufs[k].size()) free_buffers(m->abufs[k][i]);
+			if(i < (int) m->rendered[k].size() && m->rendered[k][i]) (void) hipEventDestroy(m->rendered[k][i]);
+			if(i < (int) m->gathered[k].size() && m->gathered[k][i]) (void) hipEventDestroy(m->gathered[k][i]);
+		}
+		if(i < (int) m->cstreams.size() && m->cstreams[i]) (void) hipStreamDestroy(m->cstreams[i]);
 		if(m->comms[i]) (void) rccl().CommDestroy(m->comms[i]);
 		if(m->streams[i]) (void) hipStreamDestroy(m->streams[i]);
 		if(m->renderers[i]) skr_renderer_destroy(m->renderers[i]);
@@ -523,45 +736,11 @@ int skr_multi_render_frame(skr_multi *m, const skr_options *opt, uint32_t tile_r
 	if(!m) return SKR_ERR_ARG;
 	int rc = check_frame_args(opt, tile_rows);
 	if(rc != SKR_OK) return rc;
-	{
-		std::lock_guard<std::mutex> lk(m->mu);
-		m->opt = opt;
-		m->tile_rows = tile_rows;
-		m->pending = m->n - 1;
-		m->generation++;
-	}
-	m->cv_go.notify_all();
-	m->status[0] = multi_render_rank(m, 0);
-	if(m->status[0] != SKR_OK) m->errors[0] = skr_last_error();
-	{
-		std::unique_lock<std::mutex> lk(m->mu);
-		m->cv_done.wait(lk, [&] { return m->pending == 0; });
-	}
-	for(int i = 0; i < m->n; i++)
-		if(m->status[i] != SKR_OK)
-		{
-			skr_set_error("device %d: %s", m->devices[i], m->errors[i].c_str());
-			return m->status[i];
-		}
-	if(m->comms[0])
-	{ // one collective: every rank's chunk to every rank (the root is the one that uses it), each on its rank's stream behind its kernels
-		SKR_NCCL(rccl().GroupStart());
-		for(int i = 0; i < m->n; i++)
-		{
-			RankBuffers &b = m->bufs[i];
-			const ncclResult_t ne = rccl().AllGather(b.d_gather + (size_t) i * b.chunk, b.d_gather, b.chunk, ncclUint8, m->comms[i], m->streams[i]);
-			if(ne != ncclSuccess)
-			{
-				(void) rccl().GroupEnd();
-				skr_set_error("ncclAllGather(rank %d) failed: %s", i, rccl().GetErrorString(ne));
-				return SKR_ERR_HIP;
-			}
-		}
-		SKR_NCCL(rccl().GroupEnd());
-	}
-	SKR_HIP(hipSetDevice(m->devices[0]));
-	RankBuffers &b0 = m->bufs[0];
-	SKR_HIP(launch_deinterleave(b0.d_gather, b0.d_frame, opt->width, opt->height, tile_rows, (uint32_t) m->n, b0.k_max, m->streams[0]));
+	m->async_set = -1;
+	rc = multi_render_all(m, opt, tile_rows);
+	if(rc != SKR_OK) return rc;
+	rc = multi_collect(m, m->bufs, m->streams, opt, tile_rows); // every rank's chunk to every rank (the root is the one that uses it), each on its rank's stream behind its kernels
+	if(rc != SKR_OK) return rc;
 	SKR_HIP(hipEventRecord(m->e1, m->streams[0]));
 	for(int i = m->n - 1; i >= 0; i--)
 	{
@@ -569,7 +748,91 @@ int skr_multi_render_frame(skr_multi *m, const skr_options *opt, uint32_t tile_r
 		SKR_HIP(hipStreamSynchronize(m->streams[i]));
 	}
 	if(frame_ms) SKR_HIP(hipEventElapsedTime(frame_ms, m->e0, m->e1));
-	if(d_frame) *d_frame = b0.d_frame;
+	if(d_frame) *d_frame = m->bufs[0].d_frame;
+	return SKR_OK;
+}
+
+// The pipelined form (what skr_comm_render_frame_async is to skr_comm_render_frame): frame f's all-gather and de-interleave go to a
+// second stream per device, behind an event the render stream records, while the render streams go on to frame f + 1 in the other of
+// two buffer sets.  Returns as soon as frame f is enqueued; *d_prev_frame = the frame of the PREVIOUS call, complete (its collective
+// is waited for on the host — it ran while this call's kernels were being enqueued), or NULL on the first call.
+int skr_multi_render_frame_async(skr_multi *m, const skr_options *opt, uint32_t tile_rows, uint8_t **d_prev_frame)
+{
+	if(!m) return SKR_ERR_ARG;
+	int rc = check_frame_args(opt, tile_rows);
+	if(rc != SKR_OK) return rc;
+	if(m->cstreams.empty())
+	{
+		m->cstreams.assign(m->n, nullptr);
+		for(int k = 0; k < 2; k++)
+		{
+			m->abufs[k].resize(m->n);
+			m->rendered[k].assign(m->n, nullptr);
+			m->gathered[k].assign(m->n, nullptr);
+		}
+		for(int i = 0; i < m->n; i++)
+		{
+			SKR_HIP(hipSetDevice(m->devices[i]));
+			SKR_HIP(hipStreamCreateWithFlags(&m->cstreams[i], hipStreamNonBlocking));
+			for(int k = 0; k < 2; k++)
+			{
+				SKR_HIP(hipEventCreateWithFlags(&m->rendered[k][i], hipEventDisableTiming));
+				SKR_HIP(hipEventCreateWithFlags(&m->gathered[k][i], hipEventDisableTiming));
+			}
+		}
+	}
+	const int s = (int) (m->async_frames & 1u), prev = s ^ 1;
+	if(m->in_flight[s])
+	{ // a change of geometry frees the buffers and the map the collective of frame f - 2 may still read: wait for it on the host then
+		const RankBuffers &b = m->abufs[s][0];
+		const ShardMap &mp = m->maps[0];
+		if(b.width != opt->width || b.height != opt->height || b.tile_rows != tile_rows || mp.fov != opt->fov || mp.gillum != opt->num_path_traces ||
+		   mp.depth != opt->max_depth || mp.monte_carlo != opt->monte_carlo)
+		{
+			for(int k = 0; k < 2; k++)
+				for(int i = 0; i < m->n && m->in_flight[k]; i++) SKR_HIP(hipEventSynchronize(m->gathered[k][i]));
+			m->in_flight[prev] = false; // (its frame is handed back below only if still in flight: it is gone with the old geometry)
+		}
+	}
+	m->async_set = s;
+	rc = multi_render_all(m, opt, tile_rows);
+	m->async_set = -1;
+	if(rc != SKR_OK) return rc;
+	for(int i = 0; i < m->n; i++)
+	{
+		SKR_HIP(hipSetDevice(m->devices[i]));
+		SKR_HIP(hipStreamWaitEvent(m->cstreams[i], m->rendered[s][i], 0));
+	}
+	rc = multi_collect(m, m->abufs[s], m->cstreams, opt, tile_rows);
+	if(rc != SKR_OK) return rc;
+	for(int i = 0; i < m->n; i++)
+	{
+		SKR_HIP(hipSetDevice(m->devices[i]));
+		SKR_HIP(hipEventRecord(m->gathered[s][i], m->cstreams[i]));
+	}
+	m->in_flight[s] = true;
+	m->async_frames++;
+	if(d_prev_frame)
+	{
+		*d_prev_frame = nullptr;
+		if(m->in_flight[prev])
+		{
+			SKR_HIP(hipEventSynchronize(m->gathered[prev][0]));
+			*d_prev_frame = m->abufs[prev][0].d_frame;
+		}
+	}
+	return SKR_OK;
+}
+
+// Ends a run of skr_multi_render_frame_async calls: waits for everything in flight; *d_frame = the last frame.
+int skr_multi_flush(skr_multi *m, uint8_t **d_frame)
+{
+	if(!m) return SKR_ERR_ARG;
+	if(d_frame) *d_frame = nullptr;
+	if(m->async_frames == 0) return SKR_OK;
+	for(int k = 0; k < 2; k++)
+		for(int i = 0; i < m->n && m->in_flight[k]; i++) SKR_HIP(hipEventSynchronize(m->gathered[k][i]));
+	if(d_frame) *d_frame = m->abufs[(m->async_frames - 1) & 1u][0].d_frame;
 	return SKR_OK;
 }
 
@@ -587,6 +850,49 @@ int skr_multi_render_frame_host(skr_multi *m, const skr_options *opt, uint32_t t
 uint32_t skr_shard_tiles_per_rank(int32_t height, uint32_t tile_rows, uint32_t world)
 {
 	return (height > 0 && tile_rows && world) ? tiles_per_rank(height, tile_rows, world) : 0;
+}
+
+// The cost-aware map (longest processing time first; see shard_lpt above) for callers and tests: cost[t] per tile, any unit;
+// slot_of_tile[t] = rank * k_max + slot.
+int skr_shard_lpt(const uint64_t *cost, uint32_t n_tiles, uint32_t world, uint32_t *slot_of_tile)
+{
+	if(!cost || !slot_of_tile || !n_tiles || !world) return SKR_ERR_ARG;
+	shard_lpt(cost, n_tiles, world, slot_of_tile);
+	return SKR_OK;
+}
+
+// The map a frame step of `world` ranks uses for this renderer's scene and these options (the cost probe + shard_lpt; the
+// interleaved map under SKR_SHARD=interleave or for a world of one).  Synchronous; slot_of_tile has ceil(height / tile_rows) entries.
+int skr_shard_plan(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t world, uint32_t *slot_of_tile)
+{
+	if(!r || !slot_of_tile || !world) return SKR_ERR_ARG;
+	int rc = check_frame_args(opt, tile_rows);
+	if(rc != SKR_OK) return rc;
+	const uint32_t T = tiles_total(opt->height, tile_rows);
+	if(world > 1 && lpt_wanted())
+	{
+		std::vector<uint32_t> hits(T);
+		rc = skr_tile_costs(r, opt, tile_rows, hits.data());
+		if(rc != SKR_OK) return rc;
+		std::vector<uint64_t> cost(T);
+		tile_costs_from_hits(opt, tile_rows, hits.data(), T, cost.data());
+		shard_lpt(cost.data(), T, world, slot_of_tile);
+	}
+	else shard_interleaved(T, world, slot_of_tile);
+	return SKR_OK;
+}
+
+// Host-side de-interleave of a rank-major gathered buffer under a map (what the device kernel does), for tests.
+int skr_shard_deinterleave_map_host(const uint8_t *gathered, uint8_t *frame, int32_t width, int32_t height, uint32_t tile_rows, const uint32_t *slot_of_tile)
+{
+	if(!gathered || !frame || !slot_of_tile || width <= 0 || height <= 0 || !tile_rows) return SKR_ERR_ARG;
+	const size_t row = (size_t) width * 3;
+	for(uint32_t y = 0; y < (uint32_t) height; y++)
+	{
+		const uint32_t t = y / tile_rows;
+		memcpy(frame + (size_t) y * row, gathered + ((size_t) slot_of_tile[t] * tile_rows + (y - t * tile_rows)) * row, row);
+	}
+	return SKR_OK;
 }
 
 // Host-side de-interleave of a rank-major gathered buffer (what the device kernel does), for tests and for callers that

@@ -50,47 +50,6 @@ constexpr int NWIN = 4;                     // slot windows (rounds whose contri
 constexpr int WIN_FLOATS = 2 * 3 * 64;      // [child 0|1][component][lane]
 constexpr int LEAF2_WAVE_FLOATS = NQ_CAP * NQ_F + NWIN * WIN_FLOATS;
 
-SKR_DEV uint32_t *lc_count(uint32_t *ctr, uint32_t region) { return ctr + SKR_PULL_STRIDE * region; }
-SKR_DEV uint32_t *lc_taken(uint32_t *ctr, uint32_t region) { return ctr + SKR_PULL_STRIDE * (SKR_P1_REGIONS + region); }
-SKR_DEV unsigned long long *lc_dead(uint32_t *ctr) { return reinterpret_cast<unsigned long long *>(ctr + SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS)); }
-SKR_DEV uint32_t *lc_prefix(uint32_t *ctr) { return ctr + SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS + 1u); } // 65 words: records before region r; [64] = all
-
-// the scene SoA staged into the workgroup's LDS (one __syncthreads); returns the kernel's view of it
-SKR_DEV SceneView stage_scene(const RenderParams &p, float4 *lds4, bool tris)
-{
-	const int ns = p.n_spheres, nl = p.n_lights;
-	float4 *s_geom = lds4, *s_amb = lds4 + ns + 1, *s_kd = s_amb + ns, *s_ks = s_kd + ns, *s_lights = s_ks + ns;
-	const int tid = threadIdx.x;
-	for(int i = tid; i < ns; i += 256)
-	{
-		s_geom[i] = p.sph_geom[i];
-		s_amb[i] = p.sph_amb[i];
-		s_kd[i] = p.sph_kd[i];
-		s_ks[i] = p.sph_ks[i];
-	}
-	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
-	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	__syncthreads();
-	return SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, tris ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work};
-}
-
-SKR_DEV void add_counters(const RenderParams &p, const Counters &cn, uint32_t shard, int lane)
-{
-	if(!p.counters) return;
-	const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays), d4 = wave_sum(cn.shadow_tests);
-	if(lane == 0)
-	{ // sharded: thousands of waves adding to one word serialise
-		unsigned long long *c4 = p.counters + 4u * (shard & (SKR_COUNTER_SHARDS - 1u));
-		if(a) atomicAdd(&c4[0], (unsigned long long) a);
-		if(b) atomicAdd(&c4[1], (unsigned long long) b);
-		if(c) atomicAdd(&c4[2], (unsigned long long) c);
-		if(d4) atomicAdd(&c4[3], (unsigned long long) d4);
-	}
-}
-
-struct F3p { float x, y, z; } __attribute__((packed, aligned(4)));
-SKR_DEV void store3(float *g, f3 v) { *reinterpret_cast<F3p *>(g) = F3p{v.x, v.y, v.z}; }
-
 // raytrace.h:171-186 + :189-192 / :221-224 for one traced child whose closest sphere is s: true = the child is a sphere
 // hit to be shaded; otherwise `black` says whether a triangle took it (else it left the scene)
 SKR_DEV bool classify_child(const SceneView &sv, f3 co, f3 d, float two_a, float four_a, const BestState &s, bool &black)
@@ -201,34 +160,6 @@ __global__ __launch_bounds__(256) SKR_TRACE_ATTR void skr_trace_kernel(const Ren
 	}
 	}
 	add_counters(p, cn, (uint32_t) blockIdx.x * 4u + (uint32_t) (tid >> 6), lane);
-}
-
-// Prefix sums of a level's 64 region counts (the dense numbering of its records), formed by the first wave of a workgroup
-// into 65 words of LDS: s_pre[r] = records before region r, s_pre[64] = all.  `publish`: also written behind the level's
-// counters, where the kernels launched later read the level's record count (lc_prefix_host).  Ends in a workgroup barrier.
-SKR_DEV void region_prefix(const RenderParams &p, uint32_t *s_pre, bool publish)
-{
-	if(threadIdx.x < 64)
-	{
-		const int lane = threadIdx.x;
-		const uint32_t v = *lc_count(p.rc_ctr, (uint32_t) lane);
-		uint32_t incl = v;
-#pragma unroll
-		for(int off = 1; off < 64; off <<= 1)
-		{
-			const uint32_t o = (uint32_t) __shfl_up((int) incl, off, 64);
-			if(lane >= off) incl += o;
-		}
-		s_pre[lane] = incl - v;
-		if(lane == 63) s_pre[64] = incl;
-		if(publish)
-		{
-			uint32_t *pre = lc_prefix(p.rc_ctr);
-			pre[lane] = incl - v;
-			if(lane == 63) pre[64] = incl;
-		}
-	}
-	__syncthreads();
 }
 
 // =====================================================================================================================
@@ -920,6 +851,7 @@ static bool skr_nodes_plan(const RenderParams &p, NodePlan &pl)
 // SKR_PIPELINE=nodes forces it wherever it applies; other values of SKR_PIPELINE exclude it.
 bool skr_nodes_supported(const RenderParams &p)
 {
+	if(p.shade_triangles || p.legacy_reflect) return false; // (render_generic.hip)
 	if(!(p.monte_carlo && p.n_spheres > 0 && p.n_spheres < 65536 && p.max_depth >= 2 && p.num_path_traces > 0 && p.num_path_traces <= 256)) return false;
 	NodePlan pl;
 	return skr_nodes_plan(p, pl);
@@ -931,9 +863,10 @@ bool skr_nodes_selected(const RenderParams &p)
 	if(p.sw.pipeline != SKR_PIPE_AUTO && !forced) return false;
 	if(!skr_nodes_supported(p)) return false;
 	if(forced) return true;
-	// triangle meshes at depth 2..3 stay on the parent-queue pipeline (their rounds are long and few: DESIGN.md 5.0);
-	// beyond depth 3 this is the only pipeline
-	return p.n_tris <= 64 || p.max_depth > 3;
+	// triangle meshes go to the general level pipeline (render_generic.hip: one lane per ray, one walk of the culling tree per 64
+	// rays; test.scn 640x360 --gillum 4: 1.18 ms there against 2.15 ms here, where a lane walks the tree once per sibling);
+	// a handful of triangles (spheres1.scn has two) are tested in line by the pair kernels
+	return p.n_tris <= 64;
 }
 
 // the schedule this launch takes: the flat one (small launches) or the persistent leaf kernel
@@ -990,7 +923,6 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 	const bool flat = pl.flat;
 	const int D = p.max_depth, last = flat ? D - 1 : D - 2; // record levels 1 .. last; the leaf kernel (flat: skr_shade_leaf_kernel) works on level `last`
 	const uint32_t blocks_x = (uint32_t) (p.width + 15) / 16, blocks = blocks_x * ((p.out_rows + 15) / 16);
-	p.node_layout = 1;
 	p.blocks_x = blocks_x;
 	p.stash = reinterpret_cast<float *>(base + pl.off_stash);
 	p.qctr = ctr0; // [0]: the primary kernel counts its level-0 nodes here
@@ -1000,7 +932,7 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 		p.aa_index = (uint32_t) s;
 		for(uint32_t blk0 = 0; blk0 < blocks; blk0 += pl.band_nblk)
 		{ // every band is a complete pass: its level-0 nodes, their trees, their pixels
-			const bool timed = hook && s == nsamp - 1 && blk0 + pl.band_nblk >= blocks;
+			const bool timed = hook && s == nsamp - 1 && blk0 == 0; // (the first band of the last sample: a full-size band)
 			p.band_blk0 = blk0;
 			p.band_nblk = blocks - blk0 < pl.band_nblk ? blocks - blk0 : pl.band_nblk;
 			e = hipMemsetAsync(ctr0, 0, pl.ctr_bytes, stream);

@@ -21,12 +21,9 @@ struct f3 {
 
 // The SKR_* development switches (A/B runs, tests), read from the environment ONCE per renderer (skr_renderer_create,
 // skr_renderer_reload_switches) — the launch path never calls getenv.
-enum SkrPipeline { SKR_PIPE_AUTO = 0, SKR_PIPE_NODES, SKR_PIPE_LEVELS, SKR_PIPE_QUEUE, SKR_PIPE_MEGA, SKR_PIPE_OTHER };
+enum SkrPipeline { SKR_PIPE_AUTO = 0, SKR_PIPE_NODES, SKR_PIPE_GENERIC, SKR_PIPE_OTHER };
 struct SkrSwitches {
-	int32_t pipeline = SKR_PIPE_AUTO; // SKR_PIPELINE = nodes | levels | queue | mega
-	int32_t kernel_v1 = 0;            // SKR_KERNEL = v1: the lane-per-pixel kernel
-	int32_t occ = 0;                  // SKR_OCC = 2 | 3: LDS/VGPR budget of the streaming kernels (0 = choose)
-	int32_t tile = 0;                 // SKR_TILE = 64 | 32 | 16: pixels per wave tile of the megakernel (0 = choose)
+	int32_t pipeline = SKR_PIPE_AUTO; // SKR_PIPELINE = nodes | generic: which level pipeline takes a --gillum tree (tests, A/B runs)
 	int32_t no_cones = 0, no_cull = 0; // SKR_NO_CONES, SKR_NO_CULL: triangle-walk culling off
 	int32_t budget_mb = 0;            // SKR_LEVELS_BUDGET_MB: scratch budget of the level pipelines (0 = default)
 	int32_t flat = 0;                 // SKR_FLAT = 1 | 0: the node pipeline's flat schedule forced on (+1) / off (-1); unset: by launch size
@@ -37,8 +34,8 @@ struct RenderParams {
 	// image and partition (include/skr.h skr_render_tiles)
 	int32_t width, height;
 	uint32_t tile_rows, first_tile, tile_stride, out_rows;
+	const uint32_t *tile_table; // device, or null: slot k of the compact output holds tile tile_table[k] (0xFFFFFFFF: an empty padding slot) instead of first_tile + k * tile_stride
 	uint32_t band_row0, band_rows; // skr_primary_kernel covers output rows [band_row0, band_row0 + band_rows) (the whole launch unless the level-queue pipeline works in bands)
-	int32_t tile_w_log2, tile_h_log2; // per-wave pixel tile of the streaming kernel: 8x8, 8x4 or 4x4 (set by its launcher)
 	// per-frame invariants of main.cpp:134-137, computed once on the host
 	float inv_width, inv_height, aspect, angle;
 	// camera.h:8-32 (direction/up/right keep the file's magnitudes) and scene.h:24
@@ -48,11 +45,6 @@ struct RenderParams {
 	const float4 *sph_geom, *sph_amb, *sph_kd, *sph_ks, *lights, *tris;
 	const float4 *tri_chunks; // the chunk tree of the triangle walk (scene_host.h): 3 float4 per node, depth-first, skip links, then 2 float4 per chunk
 	int32_t tri_chunk_size;
-	// level-queue pipeline (render_wave.hip): level-1 hit records, their region capacity (records), level-1 slots
-	float4 *p1;
-	float *slot1;
-	uint32_t p1_region_cap;
-	uint32_t gi_groups_per_slot, gi_group_round; // GI kernel group-size policy (set by skr_launch_queue)
 	int32_t tri_cones;        // some entry has a tight radius for non-grazing rays (else the cone test is compiled out of the walk)
 	int32_t n_tri_chunks;     // its node count; 0 = culling off (ray directions longer than the bounds were built for)
 	// utils.h:26-34 Options + scene.use_shadows
@@ -64,17 +56,13 @@ struct RenderParams {
 	float *rgbf;
 	unsigned long long *counters; // SKR_COUNTER_SHARDS x {radiance rays, sphere hits shaded, shadow rays, pad}
 	unsigned long long *tri_work; // 256 x {culling-sphere tests, triangle tests} the triangle walks executed (shade_common.h tri_work_add); null: not counted
-	// parent-queue pipeline (render_wave.hip: skr_primary_kernel -> skr_gi_kernel -> skr_resolve_kernel)
-	float4 *parents;    // 4 x float4 per primary hit: co.xyz N.x | N.yz direct.xy | direct.z kd.xyz | pixel, out_pix, -, -
-	uint32_t *qctr;     // [0] number of parents appended, [SKR_PULL_STRIDE * (1 + k)] next group of pull queue k
-	float *slot0_scratch; // per-wave level-1 contribution slots of the GI kernel (behind the parent records)
-	float *acc;         // float3 per output pixel: the running `image[y][x] += shade(...)` of main.cpp:162 (AA only)
+	uint32_t *qctr;     // [0] the number of level-0 nodes skr_primary_kernel appended
+	float *acc;         // float3 per output pixel: the running `image[y][x] += shade(...)` of main.cpp:162 (AA under --gillum: one pass per sample)
 	uint32_t aa_index;  // which AA sample this launch traces
 	// node pipeline (render_nodes.hip): the --gillum tree cut at every level.  A node is a shaded sphere hit; level 0 = the
 	// primary hits.  A node is two rows of two float4 in two arrays, so that every kernel reads only the half it needs:
 	//   geometry (tracing its children): [co.xyz N.x] [N.yz pixel node-id]                       (node id 0 at level 0)
 	//   shading  (summing them):         [direct.xyz sphere] [r1 record|output-pixel pixel node-id]   (level 0: output pixel; deeper: its own record)
-	uint32_t node_layout;     // skr_primary_kernel writes its hits as level-0 nodes (nd_dst, ns_dst) instead of 64-byte parent records
 	const float4 *nd_src;     // geometry rows of the nodes whose children are traced (trace, activate, leaf)
 	const float4 *ns_src;     // shading rows of the nodes whose children are summed (finalize, the depth-2 leaf kernel)
 	float4 *nd_dst, *ns_dst;  // nodes being written (primary hits; activated records)
@@ -94,6 +82,12 @@ struct RenderParams {
 	int32_t shade_triangles;
 	int32_t legacy_reflect;   // --legacy-reflect (lane-per-pixel kernel only): raytrace.h:45-103 runs; sph_ks[i].w = the sphere's index of refraction
 	const float4 *tri_mats;   // 3 float4 per triangle, in tris[] order: [La*ka, power] [kd] [ks] (the rows sph_amb / sph_kd / sph_ks hold for a sphere)
+	// general level pipeline (render_generic.hip): one lane per ray, every mode, any depth
+	uint32_t g_level;         // the level a launch works on (trace / activate: the rays' level, 1 = primary; finalize: the nodes' level, 0 = the camera)
+	uint32_t g_arity;         // children per node of the level whose children are traced / summed (1 at the camera level); activate: the tree's arity (node ids)
+	uint32_t g_last;          // activate: the hits of the last level (their children are shade(depth 0) == 0) are finished at once
+	const float4 *g_nodes_src; // nodes of the level above (trace, activate) / of the level being summed (finalize): 5 float4 each
+	float4 *g_nodes_dst;      // nodes being written (activate)
 };
 
 // Optional timing of the dominant kernel of a launch (skr_renderer_kernel_ms): the launcher records the

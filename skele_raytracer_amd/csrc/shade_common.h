@@ -24,7 +24,7 @@ struct SceneView {
 	int nchunks;          // nodes in the tree; 0 = walk every triangle
 	int chunk;            // triangles per chunk sphere (tri_chunks.h)
 	int cones;            // some entry carries a tight radius for non-grazing rays
-	unsigned long long *tri_work; // HBM, or null: SKR_TRI_WORK_SHARDS x {culling-sphere tests, triangle tests} the walks executed (lanes that needed them)
+	unsigned long long *tri_work; // HBM, or null (not counting): SKR_TRI_WORK_SHARDS x {culling-sphere tests, triangle tests} the walks executed (lanes that needed them)
 };
 
 // What a triangle walk executed, counted per wave on the scalar unit (population counts of lane masks the walk forms anyway) and added
@@ -143,7 +143,7 @@ SKR_DEV bool line_touches(const RayConst &r, float dd, float4 A, float4 B)
 // A line that misses a conservative sphere cannot pass the test for any triangle below it, so a node or chunk that
 // no lane's line touches is skipped whole.  The levels above the chunks are stored depth-first with skip links:
 // one wave-uniform index, no stack; both possible successors are fetched (scalar loads) while the sphere is tested.
-template <bool CONES>
+template <bool CONES, bool COUNT>
 SKR_DEV bool tree_walk(const SceneView &sv, const RayConst &r, float tmin)
 {
 	bool hit = false;
@@ -158,7 +158,7 @@ SKR_DEV bool tree_walk(const SceneView &sv, const RayConst &r, float tmin)
 		// first child (or the next node after a height-1 node) and next sibling (padded past the end)
 		const float4 A_in = sv.chunks[3 * i + 3], B_in = sv.chunks[3 * i + 4], lk_in = sv.chunks[3 * i + 5];
 		const float4 A_out = sv.chunks[3 * i_out], B_out = sv.chunks[3 * i_out + 1], lk_out = sv.chunks[3 * i_out + 2];
-		n_cull += (uint32_t) __popcll(__ballot(!hit));
+		if(COUNT) n_cull += (uint32_t) __popcll(__ballot(!hit));
 		const bool enter = __any(!hit && line_touches<CONES>(r, dd, A, B));
 		const int count = __float_as_int(lk.z);
 		if(enter && count > 0)
@@ -170,7 +170,7 @@ SKR_DEV bool tree_walk(const SceneView &sv, const RayConst &r, float tmin)
 				const float4 cA = cA_next, cB = cB_next;
 				cA_next = chunk_ent[2 * c + 2];
 				cB_next = chunk_ent[2 * c + 3];
-				n_cull += (uint32_t) __popcll(__ballot(!hit));
+				if(COUNT) n_cull += (uint32_t) __popcll(__ballot(!hit));
 				const bool mine = !hit && line_touches<CONES>(r, dd, cA, cB);
 				if(__any(mine))
 				{
@@ -183,7 +183,7 @@ SKR_DEV bool tree_walk(const SceneView &sv, const RayConst &r, float tmin)
 						n1 = sv.tris[3 * k + 4];
 						n2 = sv.tris[3 * k + 5];
 						float t;
-						n_tri += (uint32_t) __popcll(__ballot(mine && !hit));
+						if(COUNT) n_tri += (uint32_t) __popcll(__ballot(mine && !hit));
 						if(mine && !hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
 					}
 				}
@@ -195,7 +195,7 @@ SKR_DEV bool tree_walk(const SceneView &sv, const RayConst &r, float tmin)
 		B = enter ? B_in : B_out;
 		lk = enter ? lk_in : lk_out;
 	}
-	tri_work_add(sv, n_cull, n_tri);
+	if(COUNT) tri_work_add(sv, n_cull, n_tri);
 	return hit;
 }
 
@@ -205,7 +205,11 @@ SKR_DEV bool tree_walk(const SceneView &sv, const RayConst &r, float tmin)
 // loop when every active lane has.
 SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float tmin)
 {
-	if(sv.nchunks > 0) return sv.cones ? tree_walk<true>(sv, r, tmin) : tree_walk<false>(sv, r, tmin);
+	if(sv.nchunks > 0)
+	{ // (counting costs the dragon walk 19 %: the counting instantiation runs only while sv.tri_work is set — skr_renderer_count_triangle_work)
+		if(__builtin_expect(sv.tri_work != nullptr, 0)) return sv.cones ? tree_walk<true, true>(sv, r, tmin) : tree_walk<false, true>(sv, r, tmin);
+		return sv.cones ? tree_walk<true, false>(sv, r, tmin) : tree_walk<false, false>(sv, r, tmin);
+	}
 	bool hit = false;
 	uint32_t n_tri = 0;
 	// wave-uniform addresses => scalar loads; triangle i+1 is fetched while i is tested
@@ -218,7 +222,7 @@ SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float t
 		n1 = sv.tris[3 * i + 4];
 		n2 = sv.tris[3 * i + 5];
 		float t;
-		n_tri += (uint32_t) __popcll(__ballot(!hit));
+		if(sv.tri_work) n_tri += (uint32_t) __popcll(__ballot(!hit));
 		if(!hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
 		if((i & 7) == 7 && __all(hit)) break;
 	}
@@ -379,6 +383,134 @@ SKR_DEV f3 gi_direction(float r1, float r2, f3 N, f3 nt, f3 nb)
 {
 	return gi_direction_pair(r1, r2, r1, r2, N, nt, nb).d0;
 }
+
+// ---- --shade-triangles (the rules: include/skr.h skr_options.shade_triangles): the closest accepted triangle ----
+struct TriBest {
+	float t;  // smallest accepted distance so far (starts at the closest sphere's)
+	int file; // index of that triangle in the scene file, -1 = the sphere still wins
+	int slot; // its position in tris[]
+};
+
+SKR_DEV void tri_consider(const RayConst &r, bool mine, f3 v0, float4 n1, float4 n2, int slot, int from_tri, TriBest &b)
+{
+	float t;
+	if(mine && triangle_hit(r.o, r.d, v0, ld3(n1), ld3(n2), t) && t > 0.0f)
+	{
+		const int file = __float_as_int(n1.w);
+		if(file != from_tri && (t < b.t || (t == b.t && b.file >= 0 && file < b.file)))
+		{
+			b.t = t;
+			b.file = file;
+			b.slot = slot;
+		}
+	}
+}
+
+// line_touches() for the closest-hit walk: false also where every hit under the entry would lie BEHIND the running best.  A hit point
+// o + t d of an accepted triangle lies inside the entry's sphere (that is what the sphere bounds), so t |d| >= d^ . (C - o) - R:
+// with lhs = d . (C - o) - t_best (d . d) the entry cannot hold a nearer hit once lhs > R |d|.  The radii carry 16x the rounding slack
+// of the test's own u, v; the float t of a near-degenerate triangle can be off by as much again, so the entry is only skipped
+// at lhs > 1.125 R |d| (two slacks to spare).  An equal t must still be visited (the lower file index wins a tie): strict test.
+template <bool CONES>
+SKR_DEV bool entry_may_hold_nearer(const RayConst &r, float dd, float4 A, float4 B, float t_best)
+{
+	const f3 e = ld3(A) - r.o;
+	const f3 cr = cross3(e, r.d);
+	float R2 = A.w;
+	if constexpr(CONES)
+	{
+		const float gb = dot3(r.d, ld3(B));
+		R2 = (gb * gb >= dd) ? B.w : A.w;
+	}
+	const float lim = R2 * dd;
+	if(dot3(cr, cr) > lim) return false; // the line misses the sphere (NaN: falls through, "enter")
+	const float lhs = dot3(r.d, e) - t_best * dd;
+	return !(lhs > 0.0f && lhs * lhs > lim * 1.27f);
+}
+
+// The walk of tree_walk() as a closest-hit walk: every chunk whose conservative sphere this lane's line touches in front of its
+// running best is tested to the end (the spheres bound the accept test itself, whatever t comes out).
+template <bool CONES>
+SKR_DEV void tree_walk_closest(const SceneView &sv, const RayConst &r, int from_tri, TriBest &b)
+{
+	const float dd = r.two_a * 0.5f; // dot(d, d)
+	int i = 0;
+	uint32_t n_cull = 0, n_tri = 0;
+	const float4 *chunk_ent = sv.chunks + 3 * (sv.nchunks + 1);
+	float4 A = sv.chunks[0], B = sv.chunks[1], lk = sv.chunks[2];
+	while(i < sv.nchunks)
+	{
+		const int i_out = __float_as_int(lk.x);
+		const float4 A_in = sv.chunks[3 * i + 3], B_in = sv.chunks[3 * i + 4], lk_in = sv.chunks[3 * i + 5];
+		const float4 A_out = sv.chunks[3 * i_out], B_out = sv.chunks[3 * i_out + 1], lk_out = sv.chunks[3 * i_out + 2];
+		if(sv.tri_work) n_cull += (uint32_t) __popcll(__ballot(true));
+		const bool enter = __any(entry_may_hold_nearer<CONES>(r, dd, A, B, b.t));
+		const int count = __float_as_int(lk.z);
+		if(enter && count > 0)
+		{
+			const int c0 = __float_as_int(lk.y), c1 = c0 + count;
+			for(int c = c0; c < c1; c++)
+			{
+				if(sv.tri_work) n_cull += (uint32_t) __popcll(__ballot(true));
+				const bool mine = entry_may_hold_nearer<CONES>(r, dd, chunk_ent[2 * c], chunk_ent[2 * c + 1], b.t);
+				if(__any(mine))
+				{
+					const int i0 = c * sv.chunk, i1 = (i0 + sv.chunk < sv.nt) ? i0 + sv.chunk : sv.nt;
+					if(sv.tri_work) n_tri += (uint32_t) __popcll(__ballot(mine)) * (uint32_t) (i1 - i0);
+					for(int k = i0; k < i1; k++) tri_consider(r, mine, ld3(sv.tris[3 * k]), sv.tris[3 * k + 1], sv.tris[3 * k + 2], k, from_tri, b);
+				}
+			}
+		}
+		i = enter ? i + 1 : i_out;
+		A = enter ? A_in : A_out;
+		B = enter ? B_in : B_out;
+		lk = enter ? lk_in : lk_out;
+	}
+	tri_work_add(sv, n_cull, n_tri);
+}
+
+SKR_DEV void closest_triangle(const SceneView &sv, const RayConst &r, int from_tri, TriBest &b)
+{
+	if(sv.nchunks > 0)
+	{
+		if(sv.cones) tree_walk_closest<true>(sv, r, from_tri, b);
+		else tree_walk_closest<false>(sv, r, from_tri, b);
+		return;
+	}
+	for(int k = 0; k < sv.nt; k++) tri_consider(r, true, ld3(sv.tris[3 * k]), sv.tris[3 * k + 1], sv.tris[3 * k + 2], k, from_tri, b);
+}
+
+// ---- --legacy-reflect: the leaf functions of raytrace.h:45-103 ----
+// blinn_phong.h:156-184 (its unqualified sqrt is ::sqrt(double); powf(x, 2.0f) == x * x; utils.h:132-146 clamp)
+SKR_DEV float legacy_fresnel(f3 dir, f3 N, float mat_ior)
+{
+	float cos_internal = dot3(dir, N);
+	cos_internal = cos_internal < -1.0f ? -1.0f : (cos_internal > 1.0f ? 1.0f : cos_internal);
+	float et = 1.0f, ior = mat_ior;
+	if(cos_internal > 0)
+	{
+		const float t = et;
+		et = ior;
+		ior = t;
+	}
+	const float sint = (float) ((double) sk_divf(et, ior) * sqrt((double) max0(1.0f - cos_internal * cos_internal)));
+	if(sint >= 1.0f) return 1.0f;
+	const float cos_theta = (float) sqrt((double) max0(1 - sint * sint));
+	cos_internal = __builtin_fabsf(cos_internal);
+	const float Rs = sk_divf((ior * cos_internal) - (et * cos_theta), (ior * cos_internal) + (et * cos_theta));
+	const float Rp = sk_divf((et * cos_internal) - (ior * cos_theta), (ior * cos_internal) + (et * cos_theta));
+	return sk_divf(Rs * Rs + Rp * Rp, 2.0f);
+}
+
+// blinn_phong.h:143-153 refraction(): (0,0,0) on total internal reflection
+SKR_DEV f3 legacy_refraction_dir(f3 d, f3 N, float mat_ior)
+{
+	const float dn = dot3(d, N);
+	const float k = 1.0f - (mat_ior * mat_ior) * (1.0f - dn * dn);
+	return (k < 0.0f) ? mk3(0, 0, 0) : (d * mat_ior - N * (mat_ior * dn + sk_sqrtf(k)));
+}
+// blinn_phong.h:137-140 reflect_direction(): the LIGHT direction mirrored at the normal
+SKR_DEV f3 legacy_reflect_dir(f3 L, f3 N) { return normalize3(L - N * (2.0f * dot3(L, N))); }
 
 SKR_DEV uint32_t wave_sum(uint32_t v)
 {

@@ -127,6 +127,15 @@ SKR_DEV void closest_pair(const SceneView &sv, f3 o, f3 d0, f3 d1, bool second, 
 	closest_pair_deferred(sv, o, d0, d1, second, rp, s0, s1);
 }
 
+// the image row of row `orow` of the compact output (include/skr.h skr_render_tiles / skr_render_tile_list); >= height: no such row
+SKR_DEV uint32_t image_row(const RenderParams &p, uint32_t orow)
+{
+	const uint32_t k = orow / p.tile_rows;
+	const uint32_t t = p.tile_table ? p.tile_table[k] : p.first_tile + k * p.tile_stride;
+	if(t == 0xFFFFFFFFu) return 0xFFFFFFFFu;
+	return t * p.tile_rows + (orow - k * p.tile_rows);
+}
+
 SKR_DEV void primary_ray(const RenderParams &p, int x, uint32_t y, uint32_t pixel, uint32_t aa, f3 &dir)
 { // main.cpp:140-182
 	float u, v;
@@ -169,6 +178,79 @@ SKR_DEV void emit_sample(const RenderParams &p, uint32_t out_pix, f3 c)
 			o[2] = (unsigned char) quantise(c.z);
 		}
 	}
+}
+
+// ---- tables of the level pipelines (render_nodes.hip, render_generic.hip) ----
+// Hit records of a level are appended to SKR_P1_REGIONS regions (region = trace wave index mod 64: a region only receives hits of its
+// own waves); the level's counter block: [STRIDE r] records in region r, [STRIDE (64 + r)] units handed out, [STRIDE 128] the
+// exhausted-regions mask, [STRIDE 129 ..] prefix sums.
+SKR_DEV uint32_t *lc_count(uint32_t *ctr, uint32_t region) { return ctr + SKR_PULL_STRIDE * region; }
+SKR_DEV uint32_t *lc_taken(uint32_t *ctr, uint32_t region) { return ctr + SKR_PULL_STRIDE * (SKR_P1_REGIONS + region); }
+SKR_DEV unsigned long long *lc_dead(uint32_t *ctr) { return reinterpret_cast<unsigned long long *>(ctr + SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS)); }
+SKR_DEV uint32_t *lc_prefix(uint32_t *ctr) { return ctr + SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS + 1u); } // 65 words: records before region r; [64] = all
+
+// the scene SoA staged into the workgroup's LDS (one __syncthreads); returns the kernel's view of it
+SKR_DEV SceneView stage_scene(const RenderParams &p, float4 *lds4, bool tris)
+{
+	const int ns = p.n_spheres, nl = p.n_lights;
+	float4 *s_geom = lds4, *s_amb = lds4 + ns + 1, *s_kd = s_amb + ns, *s_ks = s_kd + ns, *s_lights = s_ks + ns;
+	const int tid = threadIdx.x;
+	for(int i = tid; i < ns; i += 256)
+	{
+		s_geom[i] = p.sph_geom[i];
+		s_amb[i] = p.sph_amb[i];
+		s_kd[i] = p.sph_kd[i];
+		s_ks[i] = p.sph_ks[i];
+	}
+	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
+	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	__syncthreads();
+	return SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, tris ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work};
+}
+
+SKR_DEV void add_counters(const RenderParams &p, const Counters &cn, uint32_t shard, int lane)
+{
+	if(!p.counters) return;
+	const uint32_t a = wave_sum(cn.rays), b = wave_sum(cn.hits), c = wave_sum(cn.shadow_rays), d4 = wave_sum(cn.shadow_tests);
+	if(lane == 0)
+	{ // sharded: thousands of waves adding to one word serialise
+		unsigned long long *c4 = p.counters + 4u * (shard & (SKR_COUNTER_SHARDS - 1u));
+		if(a) atomicAdd(&c4[0], (unsigned long long) a);
+		if(b) atomicAdd(&c4[1], (unsigned long long) b);
+		if(c) atomicAdd(&c4[2], (unsigned long long) c);
+		if(d4) atomicAdd(&c4[3], (unsigned long long) d4);
+	}
+}
+
+struct F3p { float x, y, z; } __attribute__((packed, aligned(4)));
+SKR_DEV void store3(float *g, f3 v) { *reinterpret_cast<F3p *>(g) = F3p{v.x, v.y, v.z}; }
+
+// Prefix sums of a level's 64 region counts (the dense numbering of its records), formed by the first wave of a workgroup
+// into 65 words of LDS: s_pre[r] = records before region r, s_pre[64] = all.  `publish`: also written behind the level's
+// counters, where the kernels launched later read the level's record count (lc_prefix_host).  Ends in a workgroup barrier.
+SKR_DEV void region_prefix(const RenderParams &p, uint32_t *s_pre, bool publish)
+{
+	if(threadIdx.x < 64)
+	{
+		const int lane = threadIdx.x;
+		const uint32_t v = *lc_count(p.rc_ctr, (uint32_t) lane);
+		uint32_t incl = v;
+#pragma unroll
+		for(int off = 1; off < 64; off <<= 1)
+		{
+			const uint32_t o = (uint32_t) __shfl_up((int) incl, off, 64);
+			if(lane >= off) incl += o;
+		}
+		s_pre[lane] = incl - v;
+		if(lane == 63) s_pre[64] = incl;
+		if(publish)
+		{
+			uint32_t *pre = lc_prefix(p.rc_ctr);
+			pre[lane] = incl - v;
+			if(lane == 63) pre[64] = incl;
+		}
+	}
+	__syncthreads();
 }
 
 } // namespace

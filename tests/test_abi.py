@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_is_gfx950_hip_code_object():
     data = open(skr.lib_path(), "rb").read()
-    assert b"gfx950" in data and b"skr_render_kernel" in data
+    assert b"gfx950" in data and all(k in data for k in (b"skr_leaf_kernel2", b"skr_direct_kernel", b"skr_gtrace_kernel"))
 
 
 def _hex(v):

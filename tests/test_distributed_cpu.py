@@ -83,3 +83,37 @@ def test_native_partition_matches_the_python_one():
         want = D.deinterleave(torch.from_numpy(g), h, tile, world).numpy()
         got = binding.shard_deinterleave_host(g, w, h, tile, world)
         assert np.array_equal(got, want)
+
+
+def test_cost_aware_tile_map_properties():
+    """libskr's cost-aware map (multi_gpu.cpp shard_lpt through skr_shard_lpt; host logic, no GPU): a permutation of the slots with
+    every rank within its k_max, deterministic, never worse balanced than dealing `t mod G`, within one tile of the mean where that
+    is possible — and the map-driven de-interleave inverts it."""
+    from skele_raytracer_amd import binding
+    rng = np.random.default_rng(5)
+    for T, G in ((135, 8), (135, 4), (135, 2), (17, 8), (7, 8), (64, 3), (1, 1)):
+        # a frame's profile: cheap sky tiles on top, tiles some 30x dearer below, noise on both
+        cost = np.where(np.arange(T) < T // 3, 15360, 400000).astype(np.uint64) + rng.integers(0, 20000, T).astype(np.uint64)
+        k_max = binding.shard_tiles_per_rank(T * 8, 8, G)
+        slot = binding.shard_lpt(cost, G)
+        assert len(set(slot.tolist())) == T and slot.max() < G * k_max              # every tile its own slot
+        per_rank = np.bincount(slot // k_max, minlength=G)
+        assert per_rank.max() <= k_max
+        assert np.array_equal(slot, binding.shard_lpt(cost, G))                     # deterministic
+        load = np.bincount(slot // k_max, weights=cost.astype(np.float64), minlength=G)
+        blind = np.bincount(np.arange(T) % G, weights=cost.astype(np.float64), minlength=G)
+        assert load.max() <= blind.max() + 1e-9
+        if T >= 4 * G:
+            assert load.max() <= cost.sum() / G + cost.max()                         # LPT's bound (slots were not binding here)
+        # the gathered buffer of that map, de-interleaved: row y of tile t sits in slot slot[t]
+        W, TR = 5, 8
+        H = T * TR - 3
+        frame = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        gathered = np.zeros((G * k_max * TR, W, 3), np.uint8)
+        for t in range(T):
+            rows = frame[t * TR:min(H, (t + 1) * TR)]
+            gathered[slot[t] * TR:slot[t] * TR + len(rows)] = rows
+        assert np.array_equal(binding.shard_deinterleave_map_host(gathered, W, H, TR, slot), frame)
+    # equal costs: still a valid map, and exactly as balanced as the blind one
+    slot = binding.shard_lpt(np.full(135, 7, np.uint64), 8)
+    assert np.bincount(slot // 17, minlength=8).max() == 17

@@ -308,13 +308,13 @@ def test_full_size_config5_rows_against_oracle(gpu, oracle):
 
 
 def test_all_kernel_variants_agree(gpu, monkeypatch):
-    """The product has one arithmetic spec and several schedules: the node pipeline (default for --gillum on sphere scenes;
-    in one band or several), the level-queue pipeline of round 1, the parent-queue pipeline, the single wave-streaming
-    megakernel with each per-wave tile shape and each LDS/VGPR budget, and the per-pixel kernel.  Every one of them must
-    produce the same bits and the same ray counts."""
+    """The product has one arithmetic spec and three schedules of a --gillum tree: the node pipeline with its persistent leaf
+    kernel (full-size frames), the node pipeline's flat schedule (small launches) — each in one band or several — and the general
+    level pipeline (one lane per ray: meshes, --shade-triangles, --legacy-reflect, here forced onto a sphere scene).  Every one
+    of them must produce the same bits and the same ray counts."""
     w, h = 176, 99
     r = renderer("spheres2.scn")
-    knobs = ("SKR_PIPELINE", "SKR_KERNEL", "SKR_OCC", "SKR_TILE", "SKR_LEVELS_BUDGET_MB", "SKR_FLAT")
+    knobs = ("SKR_PIPELINE", "SKR_LEVELS_BUDGET_MB", "SKR_FLAT")
 
     def run(opt, env):
         for k in knobs:
@@ -333,23 +333,26 @@ def test_all_kernel_variants_agree(gpu, monkeypatch):
     for env in ({"SKR_FLAT": "0"},              # the persistent leaf kernel, as on a full-size frame
                 {"SKR_LEVELS_BUDGET_MB": "2"},  # 2 MiB of tables: bands of a few 16x16 blocks (the persistent schedule: flat runs in one piece only)
                 {"SKR_FLAT": "1", "SKR_LEVELS_BUDGET_MB": "8"},  # flat forced into bands
-                {"SKR_PIPELINE": "levels"}, {"SKR_PIPELINE": "levels", "SKR_LEVELS_BUDGET_MB": "1"},
-                {"SKR_PIPELINE": "queue"}, {"SKR_PIPELINE": "queue", "SKR_OCC": "2"}, {"SKR_PIPELINE": "queue", "SKR_OCC": "3"},
-                {"SKR_PIPELINE": "mega"}, {"SKR_PIPELINE": "mega", "SKR_TILE": "64"}, {"SKR_PIPELINE": "mega", "SKR_TILE": "16"},
-                {"SKR_PIPELINE": "mega", "SKR_OCC": "2"}, {"SKR_PIPELINE": "mega", "SKR_KERNEL": "v1"}):
+                {"SKR_PIPELINE": "generic"}, {"SKR_PIPELINE": "generic", "SKR_LEVELS_BUDGET_MB": "8"}):  # the general level pipeline, whole and in bands of rows
         got = run(opt, env)
         seen.add(got[3])
         assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
         assert got[2] == base[2], env
-    assert seen == {"node_levels_v5_flat", "node_levels_v5", "level_queues_v4", "parent_queue_v3", "wave_streaming_v2", "lane_per_pixel_dfs_v1f"}
-    # depth 2 (the leaf kernel works on the primary hits) and depth 4 (one activate + trace level in between)
-    for opt2, others in ((skr.Options(w, h, gillum=8, shadow=True, depth=2, seed=31), ({"SKR_PIPELINE": "queue"}, {"SKR_PIPELINE": "mega"}, {"SKR_FLAT": "0"})),
-                         (skr.Options(96, 54, gillum=3, shadow=True, depth=4, seed=31), ({"SKR_PIPELINE": "mega", "SKR_KERNEL": "v1"}, {"SKR_LEVELS_BUDGET_MB": "8"}, {"SKR_FLAT": "0"}))):
+    assert seen == {"node_levels_v5_flat", "node_levels_v5", "level_pipeline_g1"}
+    # depth 2 (the leaf kernel works on the primary hits), depth 4 (one activate + trace level in between), depth 1 under --gillum and AA
+    for opt2, others in ((skr.Options(w, h, gillum=8, shadow=True, depth=2, seed=31), ({"SKR_PIPELINE": "generic"}, {"SKR_FLAT": "0"})),
+                         (skr.Options(96, 54, gillum=3, shadow=True, depth=4, seed=31), ({"SKR_PIPELINE": "generic"}, {"SKR_LEVELS_BUDGET_MB": "8"}, {"SKR_FLAT": "0"})),
+                         (skr.Options(96, 54, gillum=5, jsample=2, shadow=True, depth=3, seed=7), ({"SKR_PIPELINE": "generic"}, {"SKR_FLAT": "0"}))):
         b2 = run(opt2, {})
         assert b2[3] == "node_levels_v5_flat"
         for env in others:
             got = run(opt2, env)
             assert np.array_equal(got[0], b2[0]) and np.array_equal(got[1], b2[1]) and got[2] == b2[2], env
+    for opt3 in (skr.Options(w, h, gillum=8, shadow=True, depth=1, seed=31), skr.Options(w, h, jsample=3, shadow=True, seed=31)):  # no tree: the direct kernel
+        b3 = run(opt3, {})
+        assert b3[3] == "direct_v3"
+        got = run(opt3, {"SKR_PIPELINE": "generic"})
+        assert got[3] == "level_pipeline_g1" and np.array_equal(got[0], b3[0]) and np.array_equal(got[1], b3[1]) and got[2] == b3[2]
     for k in knobs:
         monkeypatch.delenv(k, raising=False)
 
@@ -380,13 +383,15 @@ def test_node_pipeline_in_bands_on_triangles_and_deep(gpu, oracle, monkeypatch):
         monkeypatch.delenv(k, raising=False)
 
 
-def test_level_queue_pipeline_in_bands_and_on_triangles(gpu, oracle, monkeypatch):
-    """Round 1's level-queue pipeline (SKR_PIPELINE=levels; kept for A/B runs) against the oracle: on a triangle scene,
-    in 16-row bands with AA (several bands x several samples), and with an odd N."""
-    for scn, w, h, kw, env in (("test.scn", 96, 54, dict(gillum=4, shadow=True, seed=3), {"SKR_PIPELINE": "levels"}),
-                               ("spheres2.scn", 200, 113, dict(gillum=6, jsample=2, shadow=True, seed=9), {"SKR_PIPELINE": "levels", "SKR_LEVELS_BUDGET_MB": "1"}),
-                               ("spheres2.scn", 131, 77, dict(gillum=5, shadow=True, seed=4), {"SKR_PIPELINE": "levels", "SKR_LEVELS_BUDGET_MB": "2"}),
-                               ("bear.scn", 160, 90, dict(gillum=255, seed=4), {"SKR_PIPELINE": "levels"})):
+def test_general_level_pipeline_on_meshes_in_bands_and_wide(gpu, oracle, monkeypatch):
+    """The general level pipeline (render_generic.hip) against the oracle where it is the product path — triangle meshes under
+    --gillum, more than 256 children per node — and in bands of rows with AA (several bands x several samples), at depth 6."""
+    for scn, w, h, kw, env, forced in (("test.scn", 96, 54, dict(gillum=4, shadow=True, seed=3), {}, False),
+                                       ("test.scn", 64, 36, dict(gillum=3, depth=6, shadow=True, seed=3), {"SKR_LEVELS_BUDGET_MB": "16"}, False),
+                                       ("dragon.scn", 96, 54, dict(gillum=4, depth=5), {}, False),
+                                       ("spheres2.scn", 200, 113, dict(gillum=6, jsample=2, shadow=True, seed=9), {"SKR_PIPELINE": "generic", "SKR_LEVELS_BUDGET_MB": "8"}, True),
+                                       ("spheres2.scn", 24, 14, dict(gillum=300, depth=2, seed=2), {}, False),
+                                       ("bear.scn", 80, 45, dict(gillum=40, depth=3, seed=4), {"SKR_PIPELINE": "generic"}, True)):
         for k in ("SKR_PIPELINE", "SKR_LEVELS_BUDGET_MB"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -395,11 +400,12 @@ def test_level_queue_pipeline_in_bands_and_on_triangles(gpu, oracle, monkeypatch
         r.counters(reset=True)
         rgb, rgbf = r.render(skr.Options(w, h, **kw), want_float=True)
         gpu.cuda.synchronize()
-        assert r.kernel_variant() == "level_queues_v4"
+        want = "direct_v3" if scn == "dragon.scn" else "level_pipeline_g1"  # (no spheres: shade() never recurses, api.cpp folds the depth)
+        assert r.kernel_variant() == want, (scn, kw, env, r.kernel_variant())
         o_rgb, o_f, st = oracle.render(scene_path(scn), w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, **kw)
         compare(rgb.cpu().numpy(), rgbf.cpu().numpy(), o_rgb, o_f, "%s %s %s" % (scn, kw, env))
         cnt = r.counters()
-        assert cnt["radiance_rays"] == int(st[0]) and cnt["sphere_hits"] == int(st[1])
+        assert cnt["radiance_rays"] == int(st[0]) and cnt["sphere_hits"] == int(st[1]) and cnt["shadow_rays"] == int(st[2])
     for k in ("SKR_PIPELINE", "SKR_LEVELS_BUDGET_MB"):
         monkeypatch.delenv(k, raising=False)
 
@@ -737,6 +743,24 @@ def test_native_frame_step_on_one_gpu(gpu, tmp_path):
     got, ms = m.render_frame_host(opt, 8)
     assert np.array_equal(got, want) and ms > 0
     assert m.counters()["radiance_rays"] > 0
+    # the pipelined form: three frames under three seeds, each handed back one call late (the last by skr_multi_flush)
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def fetch(addr):
+        out = np.zeros((h, w, 3), np.uint8)
+        assert hip.hipMemcpy(out.ctypes.data, addr, out.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        return out
+    seeds = (5, 6, 7)
+    wants = [r.render(skr.Options(w, h, gillum=4, jsample=2, shadow=True, seed=sd))[0].cpu().numpy() for sd in seeds]
+    back = []
+    for sd in seeds:
+        prev = m.render_frame_async(skr.Options(w, h, gillum=4, jsample=2, shadow=True, seed=sd), 8)
+        if prev:
+            back.append(fetch(prev))
+    back.append(fetch(m.flush()))
+    assert len(back) == 3 and all(np.array_equal(a, b) for a, b in zip(back, wants))
     m.close()
     exe = os.path.join(ROOT, "bin", "raytracer")
     args = ["--path", scene_path("spheres2.scn"), "--width", str(w), "--height", str(h), "--gillum", "4", "--jsample", "2", "--shadow", "--seed", "5", "--quiet"]
@@ -747,6 +771,43 @@ def test_native_frame_step_on_one_gpu(gpu, tmp_path):
     assert open(a, "rb").read() == open(b, "rb").read()
     res = subprocess.run([exe] + args + ["--output", b, "--gpus", "2"], capture_output=True, text=True, timeout=120)
     assert res.returncode != 0 and "visible" in res.stderr  # one GPU on this box: a loud failure, not a silent fallback
+
+
+def test_cost_aware_tile_map_renders_the_same_frame(gpu, monkeypatch):
+    """The frame steps deal the tiles by estimated cost (skr_shard_plan: the probe of skr_tile_costs + longest-processing-time-first)
+    and render each rank's list with skr_render_tile_list.  On one GPU: every rank's list of a world of 3, 4 and 8 rendered in turn
+    into its slot of a hand-made gather buffer, de-interleaved under the map — the plain frame, byte for byte; the map differs from
+    `t mod G` and balances the probe's costs better."""
+    w, h, tr = 333, 187, 8
+    opt = skr.Options(w, h, gillum=4, shadow=True, seed=11)
+    r = renderer("spheres2.scn")
+    want, _ = r.render(opt)
+    want = want.cpu().numpy()
+    T = (h + tr - 1) // tr
+    hits = r.tile_costs(opt, tr)
+    assert hits.sum() > 0 and hits[0] == 0 and hits.max() <= tr * w   # sky on top, spheres below
+    st = gpu.cuda.current_stream().cuda_stream
+    for G in (3, 4, 8):
+        monkeypatch.delenv("SKR_SHARD", raising=False)
+        slot = r.shard_plan(opt, tr, G)
+        k_max = binding.shard_tiles_per_rank(h, tr, G)
+        assert len(set(slot.tolist())) == T and not np.array_equal(slot, (np.arange(T) % G) * k_max + np.arange(T) // G)
+        gathered = gpu.zeros((G * k_max * tr, w, 3), dtype=gpu.uint8, device="cuda")
+        for rank in range(G):
+            tiles = np.full(k_max, 0xFFFFFFFF, np.uint32)
+            for t in range(T):
+                if slot[t] // k_max == rank:
+                    tiles[slot[t] % k_max] = t
+            d = gpu.from_numpy(tiles.astype(np.int64)).cuda().to(gpu.int32).contiguous()
+            r.render_tile_list_into(opt, tr, d.data_ptr(), k_max, gathered[rank * k_max * tr:].data_ptr(), None, st)
+        gpu.cuda.synchronize()
+        assert np.array_equal(binding.shard_deinterleave_map_host(gathered.cpu().numpy(), w, h, tr, slot), want), G
+        load = np.bincount(slot // k_max, weights=hits.astype(np.float64), minlength=G)
+        blind = np.bincount(np.arange(T) % G, weights=hits.astype(np.float64), minlength=G)
+        assert load.max() <= blind.max()
+        monkeypatch.setenv("SKR_SHARD", "interleave")
+        assert np.array_equal(r.shard_plan(opt, tr, G), (np.arange(T) % G) * k_max + np.arange(T) // G)
+    monkeypatch.delenv("SKR_SHARD", raising=False)
 
 
 def test_sphere_tests_are_counted_like_the_reference_runs_them(gpu, oracle):

@@ -48,6 +48,36 @@ def test_the_mode_is_what_the_readme_pictures_show(oracle):
     assert cc_h < 0.96 and mad_h > mad_l + 0.5, (mad_h, cc_h)  # HEAD's own output: 5.93, 0.952
 
 
+def test_leaf_functions_equal_the_reference_own(oracle):
+    """FUNCTION-LEVEL PIN (round 3).  The code of raytrace.h:45-103 is unreachable, but the functions it calls are ordinary ones:
+    oracle/_ref/ref_render --eval-legacy ran the reference's own bp::fresnel (blinn_phong.h:156), bp::refraction (:143) and
+    bp::reflect_direction (:137) on 10 000 (direction, normal, ior) triples (tests/golden/ref_legacy_eval.npy.gz); the oracle's
+    restatements must return the same bits.  (The composition — which rays are spawned, in which order they are summed — is
+    pinned by the four ref_*_legacy_* goldens of tests/test_oracle_golden.py: ref_driver.cpp --legacy restates only the control
+    flow and calls the reference for every value.)"""
+    import ctypes as C
+    import gzip
+    import io
+    import os
+    from conftest import GOLD
+    words = np.load(io.BytesIO(gzip.open(os.path.join(GOLD, "ref_legacy_eval.npy.gz")).read()))
+    assert words.shape == (10000, 14) and words.dtype == np.uint32
+    f = words.view(np.float32)
+    L = oracle.lib()
+    L.sko_legacy_eval.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float)]
+    L.sko_legacy_eval.restype = None
+    out = (C.c_float * 7)()
+    got = np.zeros((len(f), 7), np.float32)
+    for i, row in enumerate(f):
+        L.sko_legacy_eval((C.c_float * 3)(*row[0:3].tolist()), (C.c_float * 3)(*row[3:6].tolist()), float(row[6]), out)
+        got[i] = list(out)
+    want = words[:, 7:]
+    same = (got.view(np.uint32) == want) | (np.isnan(got) & np.isnan(f[:, 7:]))
+    assert same.all(), "first mismatch at triple %d" % int(np.argwhere(~same)[0][0])
+    # the sample covers the branches: total internal reflection (fresnel == 1 / a zero refraction direction), both signs of cos
+    assert (f[:, 7] == 1.0).sum() > 50 and ((f[:, 8:11] == 0).all(axis=1)).sum() > 50 and (f[:, 7] < 0.05).sum() > 50
+
+
 def test_depth_one_has_nothing_to_add(oracle):
     """shade(depth - 1 = 0) is (0,0,0): fr * 0 and (1 - fr) * ks * 0 add +0 to the direct term."""
     scn = scene_path("spheres2.scn")
@@ -86,7 +116,7 @@ def test_gpu_matches_the_oracle_bit_for_bit(gpu, oracle, name, scn, w, h, kw):
     r = skr.Renderer(skr.parse_scene(scene_path(scn), strict=strict))
     rgb, rgbf = r.render(skr.Options(w, h, legacy_reflect=True, **kw), want_float=True)
     gpu.cuda.synchronize()
-    assert r.kernel_variant() == "lane_per_pixel_legacy_v1r"
+    assert r.kernel_variant() == "level_pipeline_g1"
     o_rgb, o_f, st = oracle.render(scene_path(scn), w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, legacy_reflect=True, strict=strict, **kw)
     g_f = rgbf.cpu().numpy()
     nb = int((g_f.view(np.uint32) != o_f.view(np.uint32)).sum())
@@ -97,7 +127,7 @@ def test_gpu_matches_the_oracle_bit_for_bit(gpu, oracle, name, scn, w, h, kw):
     if kw.get("shadow"):
         assert cnt["shadow_rays"] == int(st[2])
     plain, _ = r.render(skr.Options(w, h, **kw))
-    assert r.kernel_variant() != "lane_per_pixel_legacy_v1r"
+    assert r.kernel_variant() != "level_pipeline_g1"
     if kw.get("depth", 3) > 1:
         assert (plain.cpu().numpy() != o_rgb).any()
 
@@ -116,17 +146,19 @@ def test_full_size_frame_against_the_readme_picture(gpu):
 
 @pytest.mark.gpu
 def test_modes_and_limits(gpu):
-    r = skr.Renderer(skr.parse_scene(scene_path("test.scn")))
-    with pytest.raises(skr.SkrError, match="choose one"):
-        r.render(skr.Options(32, 18, legacy_reflect=True, shade_triangles=True))
-    with pytest.raises(skr.SkrError, match="legacy-reflect"):
-        r.render(skr.Options(32, 18, depth=7, legacy_reflect=True))
+    from oracle import pyoracle as orc
+    r = skr.Renderer(skr.parse_scene(scene_path("spheres2.scn")))
+    # any positive --depth (main.cpp:318-329; the lane-per-pixel kernel of rounds 1-2 stopped at 6)
+    rgb, rgbf = r.render(skr.Options(40, 23, depth=9, shadow=True, legacy_reflect=True), want_float=True)
+    gpu.cuda.synchronize()
+    o_rgb, o_f, st = orc.render(scene_path("spheres2.scn"), 40, 23, rng=orc.RNG_COUNTER, math=orc.MATH_SHARED, want_float=True, depth=9, shadow=True, legacy_reflect=True)
+    assert r.kernel_variant() == "level_pipeline_g1" and (rgbf.cpu().numpy().view(np.uint32) == o_f.view(np.uint32)).all() and r.counters()["radiance_rays"] == int(st[0])
     # no spheres, nothing to reflect off: the flag is a no-op and HEAD's schedule stays
     d = skr.Renderer(skr.parse_scene(scene_path("dragon.scn")))
     a, _ = d.render(skr.Options(64, 48, legacy_reflect=True))
     b, _ = d.render(skr.Options(64, 48))
     gpu.cuda.synchronize()
-    assert gpu.equal(a, b) and d.kernel_variant() != "lane_per_pixel_legacy_v1r"
+    assert gpu.equal(a, b) and d.kernel_variant() == "direct_v3"
 
 
 @pytest.mark.gpu

@@ -35,7 +35,7 @@ CASES = [
 @pytest.mark.parametrize("name,scn,w,h,kw", CASES, ids=[c[0] for c in CASES])
 def test_shaded_triangles_match_the_oracle_bit_for_bit(gpu, oracle, name, scn, w, h, kw):
     g_rgb, g_f, cnt = gpu_render(scn, w, h, shade_triangles=True, **kw)
-    assert skr.Renderer.kernel_variant() == "lane_per_pixel_surfaces_v1s"
+    assert skr.Renderer.kernel_variant() == "level_pipeline_g1"
     o_rgb, o_f, st = oracle.render(scene_path(scn), w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, shade_triangles=True, **kw)
     compare(g_rgb, g_f, o_rgb, o_f, name)
     assert cnt["radiance_rays"] == int(st[0]) and cnt["sphere_hits"] == int(st[1])
@@ -43,7 +43,6 @@ def test_shaded_triangles_match_the_oracle_bit_for_bit(gpu, oracle, name, scn, w
         assert cnt["shadow_rays"] == int(st[2])
     # and the flag does what it says: where the default frame is black because a triangle won, this one is lit
     d_rgb, _, _ = gpu_render(scn, w, h, **kw)
-    assert skr.Renderer.kernel_variant() != "lane_per_pixel_surfaces_v1s"
     if scn != "spheres1.scn":  # (its two triangles lie where no ray of this camera goes)
         assert (d_rgb != g_rgb).any()
 
@@ -134,11 +133,16 @@ def test_scene_from_arrays_with_triangle_materials(gpu, tmp_path):
     assert (c.cpu().numpy() != a.cpu().numpy()).any()
 
 
-def test_depth_beyond_the_kernel_fails_loudly(gpu):
-    r = skr.Renderer(skr.parse_scene(scene_path("test.scn")))
-    with pytest.raises(skr.SkrError, match="shade-triangles"):
-        r.render(skr.Options(32, 18, gillum=2, depth=7, shade_triangles=True))
-    # a scene without triangles is not concerned: the flag is a no-op there and every pipeline stays available
+def test_any_depth_and_both_modes_together(gpu, oracle):
+    """main.cpp:318-329 takes any positive --depth: so does the mode (the lane-per-pixel kernel of rounds 1-2 stopped at 6), and it
+    combines with --legacy-reflect (a sphere hit has the terms of raytrace.h:45-103, a triangle hit does not)."""
+    for kw in (dict(gillum=2, depth=8, shadow=True, seed=3), dict(gillum=2, depth=3, shadow=True, seed=5, legacy_reflect=True), dict(depth=4, legacy_reflect=True)):
+        g_rgb, g_f, cnt = gpu_render("test.scn", 48, 27, shade_triangles=True, **kw)
+        assert skr.Renderer.kernel_variant() == "level_pipeline_g1"
+        o_rgb, o_f, st = oracle.render(scene_path("test.scn"), 48, 27, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, shade_triangles=True, **kw)
+        compare(g_rgb, g_f, o_rgb, o_f, str(kw))
+        assert cnt["radiance_rays"] == int(st[0]) and cnt["sphere_hits"] == int(st[1])
+    # a scene without triangles is not concerned: the flag is a no-op there and the node pipeline stays
     r2 = skr.Renderer(skr.parse_scene(scene_path("spheres2.scn")))
     a, _ = r2.render(skr.Options(32, 18, gillum=2, depth=7, seed=3, shade_triangles=True))
     assert skr.Renderer.kernel_variant().startswith("node_levels_v5")

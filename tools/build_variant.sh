@@ -8,7 +8,7 @@ FILES=${@:-render_nodes}
 make -j4 lib > /dev/null
 mkdir -p build/var_$NAME skele_raytracer_amd/lib/var
 OBJS=""
-for o in render_kernel render_wave render_nodes accumulate api scene_host multi_gpu; do
+for o in render_kernel render_wave render_nodes render_generic accumulate api scene_host multi_gpu; do
   if echo " $FILES " | grep -q " $o "; then
     src=skele_raytracer_amd/csrc/$o.hip; x=""
     [ -f $src ] || { src=skele_raytracer_amd/csrc/$o.cpp; x="-x hip"; }

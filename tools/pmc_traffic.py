@@ -13,7 +13,7 @@ import bench
 
 root, out = sys.argv[1], sys.argv[2]
 config = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-variant = sys.argv[4] if len(sys.argv) > 4 else ("node_levels_v5" if config in (3, 5) else "wave_streaming_v2")
+variant = sys.argv[4] if len(sys.argv) > 4 else ("node_levels_v5" if config in (3, 5) else "direct_v3")
 FRAMES = 6
 acc = defaultdict(lambda: defaultdict(float))   # kernel -> counter -> sum over dispatches
 launches = defaultdict(set)
