@@ -62,7 +62,7 @@ typedef struct {
 	                           * `triangle` line and the geometric normal normalize(cross(v1-v0, v2-v0)) turned against the ray;
 	                           * shadow rays still test spheres only (utils.h:42-76); the child rays of a triangle hit start at
 	                           * P + 1e-5 like a sphere's (raytrace.h:128).  No counterpart in the reference, so no reference output
-	                           * pins it (tests/test_shade_triangles.py).  Lane-per-pixel kernel, --depth <= 6. */
+	                           * pins it (tests/test_shade_triangles.py).  Any --depth, with or without --gillum (the general level pipeline). */
 	int32_t progressive_passes; /* new, default 1 (`raytracer --progressive K`, SURVEY.md 8f-4: what the SDL viewer of main.cpp:183-197 is
 	                           * for, headless).  K > 1: every render entry point traces K whole frames under the seeds seed, seed+1, ...,
 	                           * seed+K-1, sums them in binary32 in that order, divides by (float) K once and quantises the mean like
@@ -75,9 +75,10 @@ typedef struct {
 	                           * itself with depth - 1, added to the direct term as raytrace.h:102 does.  The index of refraction is the
 	                           * 14th number of the `material` line (skr_scene_set_sphere_ior for scenes from arrays; default 1).
 	                           * Children of the counter RNG's tree: arity N + 2 L (L lights); child N + 2 l = refraction of light l,
-	                           * N + 2 l + 1 = its reflection.  Unreachable at HEAD, so no output of the reference's code pins it; the
-	                           * reference's README pictures (made when it ran) are the visual check (tests/test_legacy_reflect.py).
-	                           * Lane-per-pixel kernel, --depth <= 6; not together with shade_triangles. */
+	                           * N + 2 l + 1 = its reflection.  Unreachable at HEAD, so no output of the reference's program pins it: the
+	                           * reference's own fresnel / refraction / reflect_direction functions pin the three formulas, a restated
+	                           * composition the rest, and the README pictures (made when it ran) are the visual check
+	                           * (tests/test_legacy_reflect.py).  Any --depth, with --gillum and with shade_triangles (the general level pipeline). */
 } skr_options;
 
 typedef struct {
@@ -168,9 +169,11 @@ int skr_render_tiles(skr_renderer *r, const skr_options *opt, uint32_t tile_rows
  * once the tiles are dealt by cost instead of by `t mod G`. */
 int skr_render_tile_list(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, const uint32_t *d_tiles, uint32_t n_slots,
 						 uint8_t *d_rgb, float *d_rgbf, void *stream);
-/* Per tile of tile_rows image rows, the number of its pixels whose primary ray ends on a sphere (the pixels under which a --gillum
- * tree grows): the cost estimate behind the multi-GPU tile map.  Synchronous; h_hits has ceil(height / tile_rows) entries. */
-int skr_tile_costs(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t *h_hits);
+/* Per tile of tile_rows image rows, the work it costs, counted: the tile is rendered on its own and its rays, shaded hits and
+ * ray-sphere tests (skr_renderer_read_work) are priced in flops as bench.py prices a frame.  The numbers behind the multi-GPU tile
+ * map; integer counts of a bit-reproducible render, so every rank of a job gets the same ones.  Synchronous (one small render per
+ * tile); the renderer's work counters are preserved.  h_cost has ceil(height / tile_rows) entries. */
+int skr_tile_costs(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint64_t *h_cost);
 /* Number of tiles / output rows skr_render_tiles will produce for this partition. */
 uint32_t skr_tile_count(const skr_options *opt, uint32_t tile_rows, uint32_t first_tile, uint32_t tile_stride);
 /* Contiguous rows [y0, y1) (one tile of y1-y0 rows starting at y0). */
@@ -229,9 +232,10 @@ int skr_render_progressive_host(skr_renderer *r, const skr_options *opt, uint32_
 /* ---- multi-GPU: the frame sharded over the GPUs of one node ----
  * Replaces the reference's only parallel entry, `generate_rays_parallel` (main.cpp:19-104: `#pragma omp parallel for`
  * over the rows at :33, dispatched at main.cpp:402-410) — the reference has no distributed path.
- * The framebuffer is cut into tiles of tile_rows rows; the tiles are dealt to the ranks by estimated cost (longest processing time
- * first over skr_tile_costs: sky tiles cost one ray per pixel, ground tiles a whole tree — skr_shard_plan; SKR_SHARD=interleave
- * in the environment restores rounds 1-2's `tile t to rank t mod G`); every rank renders its tiles (skr_render_tile_list) straight
+ * The framebuffer is cut into tiles of tile_rows rows and the tiles are dealt to the ranks: tile t to rank t mod G, unless the counted
+ * work of the tiles (skr_tile_costs) says that leaves the heaviest rank above 1.10 of the mean — then longest-processing-time-first
+ * over those costs (skr_shard_plan; SKR_SHARD=interleave / lpt in the environment forces one or the other).  Every rank renders its
+ * tiles (skr_render_tile_list) straight
  * into its slot of a gather buffer, ONE RCCL all-gather over xGMI brings the slots together and rank 0 de-interleaves on the device.
  * The image does not depend on G or on the map (the RNG is keyed by the global pixel).  RCCL is bound at run time;
  * skr_rccl_available() says whether it could be. */
@@ -276,11 +280,13 @@ int skr_comm_frame_to_host(skr_comm *c, uint8_t *h_rgb, void *stream);
  * buffer [world][tiles_per_rank * tile_rows][W*3] into frame[H][W*3]. */
 uint32_t skr_shard_tiles_per_rank(int32_t height, uint32_t tile_rows, uint32_t world);
 int skr_shard_deinterleave_host(const uint8_t *gathered, uint8_t *frame, int32_t width, int32_t height, uint32_t tile_rows, uint32_t world);
-/* The cost-aware map: slot_of_tile[t] = rank * k_max + slot (k_max = skr_shard_tiles_per_rank) for n_tiles tiles of cost[t] each —
- * most expensive first, each to the least loaded rank with a free slot; deterministic.  skr_shard_plan: the map a frame step of
- * `world` ranks uses for this renderer and these options (the probe + the deal).  skr_shard_deinterleave_map_host: the
- * de-interleave under such a map. */
+/* Maps: slot_of_tile[t] = rank * k_max + slot (k_max = skr_shard_tiles_per_rank) for n_tiles tiles of cost[t] each.
+ * skr_shard_lpt: most expensive tile first, each to the least loaded rank with a free slot; a rank's tiles sit in its slots in image
+ * order; deterministic.  skr_shard_by_cost: the rule of the frame steps — tile t to rank t mod world unless that leaves the heaviest
+ * rank above 1.10 of the mean cost, then skr_shard_lpt.  skr_shard_plan: the map a frame step of `world` ranks uses for this renderer
+ * and these options (skr_tile_costs + the rule).  skr_shard_deinterleave_map_host: the de-interleave under such a map. */
 int skr_shard_lpt(const uint64_t *cost, uint32_t n_tiles, uint32_t world, uint32_t *slot_of_tile);
+int skr_shard_by_cost(const uint64_t *cost, uint32_t n_tiles, uint32_t world, uint32_t *slot_of_tile);
 int skr_shard_plan(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t world, uint32_t *slot_of_tile);
 int skr_shard_deinterleave_map_host(const uint8_t *gathered, uint8_t *frame, int32_t width, int32_t height, uint32_t tile_rows, const uint32_t *slot_of_tile);
 

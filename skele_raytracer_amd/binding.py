@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "skr_kernel_variant", "skr_debug_eval",
     "skr_rccl_available", "skr_multi_create", "skr_multi_destroy", "skr_multi_device_count", "skr_multi_renderer", "skr_multi_render_frame",
     "skr_multi_render_frame_host", "skr_comm_unique_id", "skr_comm_create", "skr_comm_destroy", "skr_comm_render_frame", "skr_comm_render_frame_async", "skr_comm_flush", "skr_comm_frame_to_host",
-    "skr_shard_tiles_per_rank", "skr_shard_deinterleave_host", "skr_shard_lpt", "skr_shard_plan", "skr_shard_deinterleave_map_host", "skr_multi_render_frame_async", "skr_multi_flush",
+    "skr_shard_tiles_per_rank", "skr_shard_deinterleave_host", "skr_shard_lpt", "skr_shard_by_cost", "skr_shard_plan", "skr_shard_deinterleave_map_host", "skr_multi_render_frame_async", "skr_multi_flush",
 ]
 
 
@@ -129,6 +129,7 @@ def lib():
     L.skr_render_tile_list.argtypes = [vp, C.POINTER(COptions), C.c_uint32, vp, C.c_uint32, vp, vp, vp]
     L.skr_tile_costs.argtypes = [vp, C.POINTER(COptions), C.c_uint32, vp]
     L.skr_shard_lpt.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.skr_shard_by_cost.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.skr_shard_plan.argtypes = [vp, C.POINTER(COptions), C.c_uint32, C.c_uint32, vp]
     L.skr_shard_deinterleave_map_host.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_uint32, vp]
     L.skr_shard_tiles_per_rank.argtypes = [C.c_int32, C.c_uint32, C.c_uint32]
@@ -306,9 +307,10 @@ class Renderer:
         _check(lib().skr_render_tile_list(self.h, C.byref(opt.c), tile_rows, tiles_ptr, n_slots, rgb_ptr, rgbf_ptr, stream), "skr_render_tile_list")
 
     def tile_costs(self, opt, tile_rows):
-        """Per tile, the pixels whose primary ray ends on a sphere (include/skr.h skr_tile_costs)."""
+        """Per tile, its counted work in flops (include/skr.h skr_tile_costs)."""
+        self._sync_switches()
         n = (opt.height + tile_rows - 1) // tile_rows
-        out = np.zeros(n, np.uint32)
+        out = np.zeros(n, np.uint64)
         _check(lib().skr_tile_costs(self.h, C.byref(opt.c), tile_rows, out.ctypes.data), "skr_tile_costs")
         return out
 
@@ -521,6 +523,14 @@ def shard_lpt(cost, world):
     c = np.ascontiguousarray(cost, np.uint64)
     out = np.zeros(len(c), np.uint32)
     _check(lib().skr_shard_lpt(c.ctypes.data, len(c), world, out.ctypes.data), "skr_shard_lpt")
+    return out
+
+
+def shard_by_cost(cost, world):
+    """The frame steps' rule on given costs: `t mod world` unless that is more than 10 % off balance, then LPT (include/skr.h skr_shard_by_cost)."""
+    c = np.ascontiguousarray(cost, np.uint64)
+    out = np.zeros(len(c), np.uint32)
+    _check(lib().skr_shard_by_cost(c.ctypes.data, len(c), world, out.ctypes.data), "skr_shard_by_cost")
     return out
 
 

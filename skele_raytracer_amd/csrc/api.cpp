@@ -18,7 +18,6 @@ hipError_t skr_launch_debug(int op, const void *d_in, void *d_out, uint32_t n, h
 hipError_t skr_launch_accumulate(float *acc, const float *frame, size_t n, int first, hipStream_t stream);
 hipError_t skr_launch_resolve_accumulated(const float *acc, uint32_t passes, uint32_t width, uint32_t out_rows, uint32_t height, uint32_t tile_rows,
 										  uint32_t first_tile, uint32_t tile_stride, const uint32_t *tile_table, uint8_t *rgb, float *rgbf, hipStream_t stream);
-hipError_t skr_launch_tile_costs(const RenderParams &p, uint32_t *d_hits, hipStream_t stream); // render_wave.hip
 size_t skr_render_lds_bytes(const RenderParams &p);
 bool skr_nodes_selected(const RenderParams &p);
 size_t skr_nodes_scratch_bytes(const RenderParams &p);
@@ -462,52 +461,48 @@ int skr_render_tile_list(skr_renderer *r, const skr_options *opt, uint32_t tile_
 	return render_impl(r, opt, tile_rows, ts, d_rgb, d_rgbf, stream);
 }
 
-// Per tile of `tile_rows` image rows: the number of its pixels whose primary ray ends on a sphere — the pixels under which the
-// --gillum tree grows, i.e. what a tile costs beyond its primary rays.  Synchronous; h_hits has ceil(height / tile_rows) entries.
-int skr_tile_costs(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t *h_hits)
+// Per tile of `tile_rows` image rows: the work its pixels cost, counted — the tile is rendered on its own and the work counters read
+// (radiance rays, shaded hits, ray-sphere tests as the reference's loops run them), priced in flops like bench.py prices a frame
+// (34 per ray-sphere test, 150 per shaded hit; a ray through a triangle mesh walks ~6 chunk spheres and ~5 triangles).
+// Integer counts of a bit-reproducible render: every rank of a job computes the same numbers.  Synchronous, one small render per tile
+// (tens of milliseconds for a 1080p frame: the frame steps do it once per frame geometry); the caller's work counters are preserved.
+int skr_tile_costs(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint64_t *h_cost)
 {
-	if(!r || !opt || !h_hits || tile_rows == 0) return SKR_ERR_ARG;
+	if(!r || !opt || !h_cost || tile_rows == 0) return SKR_ERR_ARG;
 	int rc = check_options(opt);
 	if(rc != SKR_OK) return rc;
 	SKR_HIP(hipSetDevice(r->device));
 	const uint32_t T = ((uint32_t) opt->height + tile_rows - 1) / tile_rows;
-	RenderParams p{};
-	p.width = opt->width;
-	p.height = opt->height;
-	p.tile_rows = tile_rows;
-	p.first_tile = 0;
-	p.tile_stride = 1;
-	p.out_rows = T * tile_rows;
-	p.inv_width = 1 / float(opt->width);
-	p.inv_height = 1 / float(opt->height);
-	p.aspect = opt->width / float(opt->height);
-	p.angle = (float) tan(M_PI * 0.5 * opt->fov / 180.);
-	const float *c = r->info.camera;
-	p.cam_pos = f3{c[0], c[1], c[2]};
-	p.cam_dir = f3{c[3], c[4], c[5]};
-	p.cam_up = f3{c[6], c[7], c[8]};
-	p.cam_right = f3{c[9], c[10], c[11]};
-	p.n_spheres = r->info.n_spheres;
-	p.n_lights = 0;
-	p.n_tris = 0; // (a triangle in front of a sphere makes the estimate a little high: it is only an estimate)
-	p.sph_geom = r->d_blob;
-	p.sph_amb = r->d_blob + r->off_amb;
-	p.sph_kd = r->d_blob + r->off_kd;
-	p.sph_ks = r->d_blob + r->off_ks;
-	p.lights = r->d_blob + r->off_lights;
-	p.grid_size = 0; // (pixel centres)
-	uint32_t *d_hits = nullptr;
-	SKR_HIP(hipMalloc((void **) &d_hits, (size_t) T * sizeof(uint32_t)));
-	hipError_t e = hipMemset(d_hits, 0, (size_t) T * sizeof(uint32_t));
-	if(e == hipSuccess) e = skr_launch_tile_costs(p, d_hits, nullptr);
-	if(e == hipSuccess) e = hipMemcpy(h_hits, d_hits, (size_t) T * sizeof(uint32_t), hipMemcpyDeviceToHost);
-	(void) hipFree(d_hits);
+	std::vector<unsigned long long> saved((size_t) SKR_COUNTER_SHARDS * 4 + 8);
+	SKR_HIP(hipMemcpy(saved.data(), r->d_counters, saved.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	SKR_HIP(hipMemset(r->d_counters, 0, saved.size() * sizeof(unsigned long long)));
+	std::vector<uint32_t> tiles(T);
+	for(uint32_t t = 0; t < T; t++) tiles[t] = t;
+	uint32_t *d_tiles = nullptr;
+	uint8_t *d_rgb = nullptr;
+	hipError_t e = hipMalloc((void **) &d_tiles, (size_t) T * sizeof(uint32_t));
+	if(e == hipSuccess) e = hipMalloc((void **) &d_rgb, (size_t) tile_rows * (size_t) opt->width * 3);
+	if(e == hipSuccess) e = hipMemcpy(d_tiles, tiles.data(), (size_t) T * sizeof(uint32_t), hipMemcpyHostToDevice);
+	const bool was_timing = r->count_tri;
+	r->count_tri = false;
+	for(uint32_t t = 0; t < T && e == hipSuccess && rc == SKR_OK; t++)
+	{
+		rc = skr_render_tile_list(r, opt, tile_rows, d_tiles + t, 1, d_rgb, nullptr, nullptr);
+		uint64_t w[4] = {0, 0, 0, 0};
+		if(rc == SKR_OK) rc = skr_renderer_read_work(r, w, 1);
+		const uint64_t mesh = r->info.n_triangles > 64 ? (uint64_t) (6 * 19 + 5 * 46) : (uint64_t) r->info.n_triangles * 46;
+		h_cost[t] = 34 * w[3] + 150 * w[1] + (20 + mesh) * (w[0] + w[2]);
+	}
+	r->count_tri = was_timing;
+	if(d_tiles) (void) hipFree(d_tiles);
+	if(d_rgb) (void) hipFree(d_rgb);
+	if(e == hipSuccess) e = hipMemcpy(r->d_counters, saved.data(), saved.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
 	if(e != hipSuccess)
 	{
 		skr_set_error("skr_tile_costs: %s", hipGetErrorString(e));
 		return SKR_ERR_HIP;
 	}
-	return SKR_OK;
+	return rc;
 }
 
 int skr_accumulate(float *d_acc, const float *d_frame, uint64_t n_floats, int first, void *stream)

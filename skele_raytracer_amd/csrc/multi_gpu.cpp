@@ -96,14 +96,14 @@ Rccl &rccl()
 uint32_t tiles_total(int32_t height, uint32_t tile_rows) { return ((uint32_t) height + tile_rows - 1) / tile_rows; }
 uint32_t tiles_per_rank(int32_t height, uint32_t tile_rows, uint32_t world) { return (tiles_total(height, tile_rows) + world - 1) / world; }
 
-// The tile -> (rank, slot) map.  Tiles differ in cost by an order of magnitude (sky rows: one ray per pixel; ground rows: a tree of up
-// to 1 + N + N^2 rays under every pixel), and dealing them out blindly (tile t to rank t mod G, rounds 1-2) left the slowest of 8
-// ranks 30 % above the mean.  Here every tile has a cost estimate — its pixels plus, for every pixel whose primary ray ends on a
-// sphere (counted by skr_tile_costs: a 0.1 ms kernel, once per frame geometry), the tree under it — and the tiles are dealt by
-// longest-processing-time-first: most expensive tile first, each to the rank with the least work so far that still has a free slot
-// (every rank has k_max = ceil(T / G) slots: the all-gather moves equal chunks).  Deterministic — integer counts, a stable sort,
-// ties to the lower index — so every rank of a job computes the same map without talking to the others.
-// slot_of_tile[t] = rank * k_max + k.  The image cannot change with the map: the RNG is keyed by the global pixel.
+// The tile -> (rank, slot) map: slot_of_tile[t] = rank * k_max + k; every rank has k_max = ceil(T / G) slots (the all-gather moves
+// equal chunks).  Tiles differ in cost by an order of magnitude (sky rows: one ray per pixel; ground rows: a tree of up to
+// 1 + N + N^2 rays under every pixel).  Two ways to deal them: blindly, tile t to rank t mod G (the tiles are a few rows high, so every
+// rank gets a sample of the whole image), and by cost — every tile's own counted work (skr_tile_costs renders each tile once and reads
+// the work counters, once per frame geometry), dealt longest-processing-time-first: most expensive tile first, each to the rank with
+// the least work so far that still has a free slot.  Both are deterministic (integer counts of a bit-reproducible render, a stable
+// sort, ties to the lower index), so every rank of a job computes the same map without talking to the others, and the image cannot
+// change with the map: the RNG is keyed by the global pixel.  shard_rule() below says which one a frame step takes.
 void shard_interleaved(uint32_t T, uint32_t world, uint32_t *slot_of_tile)
 {
 	const uint32_t k_max = (T + world - 1) / world;
@@ -124,27 +124,17 @@ void shard_lpt(const uint64_t *cost, uint32_t T, uint32_t world, uint32_t *slot_
 		uint32_t best = world;
 		for(uint32_t r = 0; r < world; r++)
 			if(used[r] < k_max && (best == world || load[r] < load[best])) best = r;
-		slot_of_tile[t] = best * k_max + used[best];
+		slot_of_tile[t] = best; // (the rank for now)
 		used[best]++;
 		load[best] += cost[t];
 	}
-}
-
-// what a tile costs, in primary-ray units: its pixels, plus for every pixel with a sphere under it the rays of the tree below
-// (a child ray hits a sphere about one time in three in the reference's scenes; a shaded hit costs about two more rays' worth)
-void tile_costs_from_hits(const skr_options *opt, uint32_t tile_rows, const uint32_t *hits, uint32_t T, uint64_t *cost)
-{
-	double tree = 0, level = 1;
-	if(opt->monte_carlo && opt->num_path_traces > 0)
-		for(int k = 1; k < opt->max_depth && k < 8; k++)
-		{
-			level *= (double) opt->num_path_traces * (k == 1 ? 1.0 : 0.33);
-			tree += level;
-		}
+	// a rank's tiles sit in its slots in image order, as under the blind map: the kernels cut a launch into regions of consecutive
+	// blocks, and dealing the slots in LPT order (all the expensive tiles first) cost 4 % of a share's time
+	std::fill(used.begin(), used.end(), 0u);
 	for(uint32_t t = 0; t < T; t++)
 	{
-		const uint32_t rows = (t + 1) * tile_rows <= (uint32_t) opt->height ? tile_rows : (uint32_t) opt->height - t * tile_rows;
-		cost[t] = (uint64_t) rows * (uint64_t) opt->width + (uint64_t) ((double) hits[t] * (2.0 + tree));
+		const uint32_t r = slot_of_tile[t];
+		slot_of_tile[t] = r * k_max + used[r]++;
 	}
 }
 
@@ -191,10 +181,55 @@ struct ShardMap {
 	uint32_t *d_slot_of_tile = nullptr; // T entries
 };
 
-bool lpt_wanted()
-{ // SKR_SHARD=interleave: the blind map of rounds 1-2 (A/B runs, tests)
+// Which map a frame step takes.  Measured on the headline frame (tools/time_shard.py, profiles/r03_time_shard.txt): the blind map's
+// slowest rank of 8 is 3 % above the mean, and LPT over the counted work does not beat it — ranks whose counted rays, hits and
+// ray-sphere tests agree to 0.1 % still differ by 6 % in time when one of them holds the expensive tiles of ONE part of the image
+// (what LPT deals first) and the other tiles from all over it.  So interleaving stays the rule, and the counted costs decide only
+// whether it is safe: where the blind map's heaviest rank carries more than 1.10 of the mean cost (a frame whose expensive rows repeat
+// with a period of G tiles; few tiles per rank), LPT takes over.  SKR_SHARD=interleave / lpt forces one or the other.
+enum ShardRule { SHARD_AUTO, SHARD_INTERLEAVE, SHARD_LPT };
+ShardRule shard_rule()
+{
 	const char *e = getenv("SKR_SHARD");
-	return !(e && !strcmp(e, "interleave"));
+	if(e && !strcmp(e, "interleave")) return SHARD_INTERLEAVE;
+	if(e && !strcmp(e, "lpt")) return SHARD_LPT;
+	return SHARD_AUTO;
+}
+
+// true = the blind map leaves its heaviest rank above 1.10 of the mean cost
+bool interleave_unbalanced(const uint64_t *cost, uint32_t T, uint32_t world)
+{
+	std::vector<uint64_t> load(world, 0);
+	uint64_t total = 0;
+	for(uint32_t t = 0; t < T; t++)
+	{
+		load[t % world] += cost[t];
+		total += cost[t];
+	}
+	const uint64_t heaviest = *std::max_element(load.begin(), load.end());
+	return (long double) heaviest * world * 100 > (long double) total * 110;
+}
+
+void shard_by_cost(const uint64_t *cost, uint32_t T, uint32_t world, ShardRule rule, uint32_t *slot_of_tile)
+{
+	if(rule == SHARD_LPT || (rule == SHARD_AUTO && interleave_unbalanced(cost, T, world))) shard_lpt(cost, T, world, slot_of_tile);
+	else shard_interleaved(T, world, slot_of_tile);
+}
+
+int plan_map(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t world, uint32_t *slot_of_tile)
+{
+	const uint32_t T = tiles_total(opt->height, tile_rows);
+	const ShardRule rule = shard_rule();
+	if(world < 2 || rule == SHARD_INTERLEAVE)
+	{
+		shard_interleaved(T, world, slot_of_tile);
+		return SKR_OK;
+	}
+	std::vector<uint64_t> cost(T);
+	const int rc = skr_tile_costs(r, opt, tile_rows, cost.data());
+	if(rc != SKR_OK) return rc;
+	shard_by_cost(cost.data(), T, world, rule, slot_of_tile);
+	return SKR_OK;
 }
 
 void free_map(ShardMap &m)
@@ -228,16 +263,8 @@ int ensure_map(ShardMap &m, skr_renderer *r, const skr_options *opt, uint32_t ti
 	else
 	{
 		m.slot_of_tile.assign(m.T, 0);
-		if(world > 1 && lpt_wanted())
-		{
-			std::vector<uint32_t> hits(m.T);
-			const int rc = skr_tile_costs(r, opt, tile_rows, hits.data());
-			if(rc != SKR_OK) return rc;
-			std::vector<uint64_t> cost(m.T);
-			tile_costs_from_hits(opt, tile_rows, hits.data(), m.T, cost.data());
-			shard_lpt(cost.data(), m.T, world, m.slot_of_tile.data());
-		}
-		else shard_interleaved(m.T, world, m.slot_of_tile.data());
+		const int rc = plan_map(r, opt, tile_rows, world, m.slot_of_tile.data());
+		if(rc != SKR_OK) return rc;
 	}
 	std::vector<uint32_t> mine(m.k_max, 0xFFFFFFFFu);
 	for(uint32_t t = 0; t < m.T; t++)
@@ -861,24 +888,20 @@ int skr_shard_lpt(const uint64_t *cost, uint32_t n_tiles, uint32_t world, uint32
 	return SKR_OK;
 }
 
-// The map a frame step of `world` ranks uses for this renderer's scene and these options (the cost probe + shard_lpt; the
-// interleaved map under SKR_SHARD=interleave or for a world of one).  Synchronous; slot_of_tile has ceil(height / tile_rows) entries.
+// The map a frame step of `world` ranks uses for this renderer's scene and these options (plan_map above).  Synchronous; slot_of_tile has ceil(height / tile_rows) entries.
 int skr_shard_plan(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, uint32_t world, uint32_t *slot_of_tile)
 {
 	if(!r || !slot_of_tile || !world) return SKR_ERR_ARG;
 	int rc = check_frame_args(opt, tile_rows);
 	if(rc != SKR_OK) return rc;
-	const uint32_t T = tiles_total(opt->height, tile_rows);
-	if(world > 1 && lpt_wanted())
-	{
-		std::vector<uint32_t> hits(T);
-		rc = skr_tile_costs(r, opt, tile_rows, hits.data());
-		if(rc != SKR_OK) return rc;
-		std::vector<uint64_t> cost(T);
-		tile_costs_from_hits(opt, tile_rows, hits.data(), T, cost.data());
-		shard_lpt(cost.data(), T, world, slot_of_tile);
-	}
-	else shard_interleaved(T, world, slot_of_tile);
+	return plan_map(r, opt, tile_rows, world, slot_of_tile);
+}
+
+// The rule of the frame steps on given costs (tests): the blind map unless it leaves its heaviest rank above 1.10 of the mean cost.
+int skr_shard_by_cost(const uint64_t *cost, uint32_t n_tiles, uint32_t world, uint32_t *slot_of_tile)
+{
+	if(!cost || !slot_of_tile || !n_tiles || !world) return SKR_ERR_ARG;
+	shard_by_cost(cost, n_tiles, world, SHARD_AUTO, slot_of_tile);
 	return SKR_OK;
 }
 

@@ -239,34 +239,6 @@ __global__ __launch_bounds__(256) void skr_resolve_kernel(const RenderParams p)
 	}
 }
 
-// What a tile of the frame will cost, before it is rendered (the cost-aware tile -> rank map of multi_gpu.cpp): one lane per pixel,
-// the primary ray at the pixel centre against the spheres; hits[t] = pixels of tile t whose ray ends on a sphere — the pixels under
-// which a --gillum tree grows.  (Integer counts of a deterministic test: every rank computes the same numbers.)
-__global__ __launch_bounds__(256) void skr_tile_cost_kernel(const RenderParams p, uint32_t *hits)
-{
-	extern __shared__ __align__(16) unsigned char lds_raw[];
-	const SceneView sv = stage_scene(p, reinterpret_cast<float4 *>(lds_raw), false);
-	const int x = (int) (blockIdx.x * 64u + (threadIdx.x & 63));
-	const uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6);
-	bool hit = false;
-	if(x < p.width && y < (uint32_t) p.height)
-	{
-		f3 dir;
-		primary_ray(p, x, y, y * (uint32_t) p.width + (uint32_t) x, 0u, dir);
-		float tmin;
-		hit = closest_sphere(sv, make_ray(p.cam_pos, dir), tmin) >= 0;
-	}
-	const unsigned long long m = __ballot(hit); // (a wave = 64 pixels of one row: one tile)
-	if((threadIdx.x & 63) == 0 && m && y < (uint32_t) p.height) atomicAdd(&hits[y / p.tile_rows], (uint32_t) __popcll(m));
-}
-
-hipError_t skr_launch_tile_costs(const RenderParams &p, uint32_t *d_hits, hipStream_t stream)
-{
-	const size_t lds = ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 32;
-	hipLaunchKernelGGL(skr_tile_cost_kernel, dim3((unsigned) ((p.width + 63) / 64), (unsigned) ((p.height + 3) / 4)), dim3(256), lds, stream, p, d_hits);
-	return hipGetLastError();
-}
-
 // the direct kernel's workgroup: the scene + 4 x 192 bytes of tile — and, for meshes, padding up to a third of the CU's LDS: the
 // triangle walk of dragon.scn runs 2.05 / 1.31 / 1.28 / 1.36 ms at 1 / 2 / 3 / 4+ waves per SIMD (measured), spheres2 --jsample 5
 // 1.83 / 1.63 ms at 3 / 4+

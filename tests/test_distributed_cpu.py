@@ -114,6 +114,21 @@ def test_cost_aware_tile_map_properties():
             rows = frame[t * TR:min(H, (t + 1) * TR)]
             gathered[slot[t] * TR:slot[t] * TR + len(rows)] = rows
         assert np.array_equal(binding.shard_deinterleave_map_host(gathered, W, H, TR, slot), frame)
+        # within a rank the tiles keep their image order
+        for rank in range(G):
+            mine = np.flatnonzero(slot // k_max == rank)
+            assert np.array_equal(np.sort(slot[mine]), slot[mine])
     # equal costs: still a valid map, and exactly as balanced as the blind one
     slot = binding.shard_lpt(np.full(135, 7, np.uint64), 8)
     assert np.bincount(slot // 17, minlength=8).max() == 17
+    # the frame steps' rule: the blind map while it is within 10 % of balance (a smooth profile), LPT where it is not (expensive rows
+    # that repeat with the period of the deal)
+    T, G = 135, 8
+    blind = (np.arange(T) % G) * 17 + np.arange(T) // G
+    smooth = (np.where(np.arange(T) < 45, 15360, 400000) + 50 * np.arange(T)).astype(np.uint64)
+    assert np.array_equal(binding.shard_by_cost(smooth, G), blind)
+    periodic = np.where(np.arange(T) % G == 3, 900000, 20000).astype(np.uint64)
+    slot = binding.shard_by_cost(periodic, G)
+    assert np.array_equal(slot, binding.shard_lpt(periodic, G)) and not np.array_equal(slot, blind)
+    load = np.bincount(slot // 17, weights=periodic.astype(np.float64), minlength=G)
+    assert load.max() < 0.3 * np.bincount(np.arange(T) % G, weights=periodic.astype(np.float64), minlength=G).max()

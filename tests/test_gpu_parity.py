@@ -774,39 +774,44 @@ def test_native_frame_step_on_one_gpu(gpu, tmp_path):
 
 
 def test_cost_aware_tile_map_renders_the_same_frame(gpu, monkeypatch):
-    """The frame steps deal the tiles by estimated cost (skr_shard_plan: the probe of skr_tile_costs + longest-processing-time-first)
-    and render each rank's list with skr_render_tile_list.  On one GPU: every rank's list of a world of 3, 4 and 8 rendered in turn
-    into its slot of a hand-made gather buffer, de-interleaved under the map — the plain frame, byte for byte; the map differs from
-    `t mod G` and balances the probe's costs better."""
+    """The frame steps deal the tiles `t mod G` unless the counted work of the tiles (skr_tile_costs) says that is more than 10 % off
+    balance, then longest-processing-time-first (skr_shard_plan), and render each rank's list with skr_render_tile_list.  On one GPU:
+    every rank's list of a world of 3, 4 and 8 under the forced LPT map and under the rule's, rendered in turn into its slot of a
+    hand-made gather buffer, de-interleaved under the map — the plain frame, byte for byte."""
     w, h, tr = 333, 187, 8
     opt = skr.Options(w, h, gillum=4, shadow=True, seed=11)
     r = renderer("spheres2.scn")
     want, _ = r.render(opt)
     want = want.cpu().numpy()
     T = (h + tr - 1) // tr
-    hits = r.tile_costs(opt, tr)
-    assert hits.sum() > 0 and hits[0] == 0 and hits.max() <= tr * w   # sky on top, spheres below
+    r.work(reset=True)
+    cost = r.tile_costs(opt, tr)
+    assert cost.min() > 0 and cost.max() > 10 * cost[0]   # sky on top (one ray per pixel, against every sphere), spheres and their trees below
+    assert r.work()["radiance_rays"] == 0                 # (the probe leaves the caller's counters alone)
     st = gpu.cuda.current_stream().cuda_stream
     for G in (3, 4, 8):
-        monkeypatch.delenv("SKR_SHARD", raising=False)
-        slot = r.shard_plan(opt, tr, G)
         k_max = binding.shard_tiles_per_rank(h, tr, G)
-        assert len(set(slot.tolist())) == T and not np.array_equal(slot, (np.arange(T) % G) * k_max + np.arange(T) // G)
-        gathered = gpu.zeros((G * k_max * tr, w, 3), dtype=gpu.uint8, device="cuda")
-        for rank in range(G):
-            tiles = np.full(k_max, 0xFFFFFFFF, np.uint32)
-            for t in range(T):
-                if slot[t] // k_max == rank:
-                    tiles[slot[t] % k_max] = t
-            d = gpu.from_numpy(tiles.astype(np.int64)).cuda().to(gpu.int32).contiguous()
-            r.render_tile_list_into(opt, tr, d.data_ptr(), k_max, gathered[rank * k_max * tr:].data_ptr(), None, st)
-        gpu.cuda.synchronize()
-        assert np.array_equal(binding.shard_deinterleave_map_host(gathered.cpu().numpy(), w, h, tr, slot), want), G
-        load = np.bincount(slot // k_max, weights=hits.astype(np.float64), minlength=G)
-        blind = np.bincount(np.arange(T) % G, weights=hits.astype(np.float64), minlength=G)
-        assert load.max() <= blind.max()
-        monkeypatch.setenv("SKR_SHARD", "interleave")
-        assert np.array_equal(r.shard_plan(opt, tr, G), (np.arange(T) % G) * k_max + np.arange(T) // G)
+        blind = (np.arange(T) % G) * k_max + np.arange(T) // G
+        for rule in ("lpt", None, "interleave"):
+            if rule: monkeypatch.setenv("SKR_SHARD", rule)
+            else: monkeypatch.delenv("SKR_SHARD", raising=False)
+            slot = r.shard_plan(opt, tr, G)
+            assert len(set(slot.tolist())) == T
+            if rule == "lpt": assert np.array_equal(slot, binding.shard_lpt(cost, G)) and not np.array_equal(slot, blind)
+            elif rule == "interleave": assert np.array_equal(slot, blind)
+            else: assert np.array_equal(slot, binding.shard_by_cost(cost, G))
+            gathered = gpu.zeros((G * k_max * tr, w, 3), dtype=gpu.uint8, device="cuda")
+            for rank in range(G):
+                tiles = np.full(k_max, 0xFFFFFFFF, np.uint32)
+                for t in range(T):
+                    if slot[t] // k_max == rank:
+                        tiles[slot[t] % k_max] = t
+                d = gpu.from_numpy(tiles.astype(np.int64)).cuda().to(gpu.int32).contiguous()
+                r.render_tile_list_into(opt, tr, d.data_ptr(), k_max, gathered[rank * k_max * tr:].data_ptr(), None, st)
+            gpu.cuda.synchronize()
+            assert np.array_equal(binding.shard_deinterleave_map_host(gathered.cpu().numpy(), w, h, tr, slot), want), (G, rule)
+            load = np.bincount(slot // k_max, weights=cost.astype(np.float64), minlength=G)
+            assert load.max() <= np.bincount(np.arange(T) % G, weights=cost.astype(np.float64), minlength=G).max()
     monkeypatch.delenv("SKR_SHARD", raising=False)
 
 

@@ -30,9 +30,12 @@ def time_rank(tiles, k_max):
 
 whole = time_rank(np.arange(T, dtype=np.uint32), T)
 print("G=1: %.3f ms" % whole, flush=True)
-for G in (2, 4, 8):
+GS = [int(g) for g in os.environ.get("G_LIST", "2,4,8").split(",")]
+MODES = os.environ.get("MODES", "lpt,interleave").split(",")
+for G in GS:
     k_max = binding.shard_tiles_per_rank(1080, TR, G)
-    for name, env in (("cost-aware (LPT)", None), ("t mod G", "interleave")):
+    for name, env in (("cost-aware (LPT)", "lpt"), ("t mod G", "interleave")):
+        if env not in MODES: continue
         if env: os.environ["SKR_SHARD"] = env
         else: os.environ.pop("SKR_SHARD", None)
         slot = r.shard_plan(opt, TR, G)
@@ -42,5 +45,12 @@ for G in (2, 4, 8):
             for t in range(T):
                 if slot[t] // k_max == rank: tiles[slot[t] % k_max] = t
             times.append(time_rank(tiles, k_max))
+            if os.environ.get("PRINT_WORK"):
+                r.work(reset=True)
+                time_rank.__globals__["r"].render_tile_list_into(opt, TR, torch.from_numpy(tiles.astype(np.int64)).cuda().to(torch.int32).contiguous().data_ptr(), k_max,
+                                                                 torch.zeros((k_max * TR, 1920, 3), dtype=torch.uint8, device="cuda").data_ptr(), None, st.cuda_stream)
+                torch.cuda.synchronize()
+                wk = r.work(reset=True)
+                print("WORK G=%d %s rank %d tiles %d time %.4f %s" % (G, env, rank, int((tiles != 0xFFFFFFFF).sum()), times[-1], " ".join("%s=%d" % kv for kv in sorted(wk.items()))), flush=True)
         print("G=%d %-18s slowest rank %.3f ms, mean %.3f ms, ranks %s  -> %.2fx of G=1 before the collective" % (G, name, max(times), sum(times) / G, " ".join("%.3f" % t for t in times), whole / max(times)), flush=True)
 os.environ.pop("SKR_SHARD", None)
