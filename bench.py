@@ -249,6 +249,15 @@ def main():
         if not ok:
             fail("libskr's RCCL frame step could not be set up on every rank (%s); run with --torch-gather to measure the torch.distributed step instead" % (err or "another rank failed"))
     sharder = None if comm is not None else FrameSharder(W, H, TILE_ROWS, rank, world, dev)
+    if comm is not None and world > 1:
+        T_all = (H + TILE_ROWS - 1) // TILE_ROWS
+        plan = r.shard_plan(opt, TILE_ROWS, world)  # (what the frame steps use: skr_shard_plan)
+        blind = (np.arange(T_all) % world) * k_max + np.arange(T_all) // world
+        tile_map_name = "tile t -> rank t mod G (the counted tile costs leave it within 10 % of balance)" if np.array_equal(plan, blind) else "longest-processing-time-first over the counted tile costs"
+        if os.environ.get("SKR_SHARD"):
+            tile_map_name += " [SKR_SHARD=%s]" % os.environ["SKR_SHARD"]
+    else:
+        tile_map_name = "tile t -> rank t mod G"
 
     # (at N = 1 there is no collective to hide and the two extra stream waits cost 1 %: measured 1.796 against 1.779 ms)
     pipelined = comm is not None and (world > 1 or args.async_frames) and not args.sync_frames
@@ -294,11 +303,47 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
+    cnt = r.work(reset=True)
+
+    # the other frame step of the library beside the timed one, over a short pass of its own (outside the timed region): the serial step
+    # (collective on the render stream) when the pipelined one was timed and the other way round — so that a run on G GPUs shows what
+    # the pipelining buys.  Same barrier + synchronize bracket, MAX over ranks below.
+    other_ms, other_name = None, None
+    if comm is not None and (world > 1 or args.async_frames or args.sync_frames):
+        n_other = min(args.steps, 100)
+        if pipelined:
+            other_name = "skr_comm_render_frame (serial: collective on the render stream)"
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(n_other):
+                comm.render_frame(opt, TILE_ROWS, stream.cuda_stream)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            other_ms = (time.perf_counter() - t1) / n_other * 1e3
+        else:
+            other_name = "skr_comm_render_frame_async (pipelined: collective of frame f behind the render of frame f + 1)"
+            try:
+                comm.render_frame_async(opt, TILE_ROWS, stream.cuda_stream, want_previous=False)
+                comm.flush(stream.cuda_stream)
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(n_other):
+                    comm.render_frame_async(opt, TILE_ROWS, stream.cuda_stream, want_previous=False)
+                comm.flush(stream.cuda_stream)
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize(dev)
+                other_ms = (time.perf_counter() - t1) / n_other * 1e3
+            except skr.SkrError as e:
+                fail("the pipelined frame step failed in the side pass (%s)" % str(e)[:200])
+        r.work(reset=True)
 
     variant = r.kernel_variant()
     queued = r.last_parent_count()
     level1 = r.last_level1_count()
-    cnt = r.work(reset=True)
     # the dominant kernel alone: HIP events on its stream around every launch of a short extra pass (not in the timed region),
     # and the work counters copied in front of and behind it (skr_renderer_kernel_work)
     r.kernel_timing(True)
@@ -333,7 +378,7 @@ def main():
         tri = {k: v * args.steps for k, v in tri.items()}
 
     stats = torch.tensor([dt, float(cnt["radiance_rays"]), float(cnt["shadow_rays"]), float(cnt["sphere_hits"]), float(cnt["sphere_tests"]), kernel_ms, pipeline_ms,
-                          float(tri["cull_tests"]), float(tri["triangle_tests"]), float(tri["reference_triangle_tests"])],
+                          float(tri["cull_tests"]), float(tri["triangle_tests"]), float(tri["reference_triangle_tests"]), float(other_ms or 0.0)],
                          dtype=torch.float64, device=dev if not rehearsal else "cpu")
     if world > 1:
         mx = stats.clone()
@@ -341,6 +386,8 @@ def main():
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt, kernel_ms, pipeline_ms = float(mx[0]), float(mx[5]), float(mx[6])
+        if other_ms is not None:
+            other_ms = float(mx[10])
         tot = sm
     else:
         tot = stats
@@ -390,11 +437,15 @@ def main():
                        "shadow_rays_per_frame": shadow / n, "sphere_tests_per_frame": tests / n, "shaded_hits_per_frame": hits / n,
                        "triangle_tests_executed_per_frame": tri_tests / n, "culling_sphere_tests_executed_per_frame": cull_tests / n,
                        "triangle_tests_of_the_reference_loop_per_frame": tri_tests_ref / n,
-                       "partition": "interleaved %d-row tiles, rank = tile %% %d" % (TILE_ROWS, world),
+                       "partition": "%d-row tiles over %d rank(s)" % (TILE_ROWS, world),
                        "frame_step": ("REHEARSAL on one GPU over gloo - not a measurement" if rehearsal else
                                       (("libskr skr_comm_render_frame_async: tiles -> ncclAllGather (RCCL, in the library) -> de-interleave kernel on rank 0, the collective of frame f on its own stream behind the render of frame f + 1; the last frame's collective inside the timed region" if pipelined else "libskr skr_comm_render_frame: tiles -> ncclAllGather (RCCL, in the library) -> de-interleave kernel on rank 0") if comm is not None else
                                        "torch.distributed all_gather_into_tensor of the u8 tile buffers, rank 0 de-interleaves (torch) [--torch-gather]")) if world > 1
                                      else (("libskr skr_comm_render_frame_async (1 GPU: tiles, then the de-interleave kernel on the communicator's stream; no collective)" if pipelined else "libskr skr_comm_render_frame (1 GPU: tiles + de-interleave kernel, no collective)") if comm is not None else "skr_render_tiles + torch de-interleave [--torch-gather]"),
+                       "frame_steps_ms": ({"timed": ms_per_step, "timed_step": "pipelined" if pipelined else "serial", "other": other_ms, "other_step": other_name,
+                                           "render_only": pipeline_ms, "note": "`other` and `render_only` come from short passes outside the timed region (MAX over ranks)"}
+                                          if other_ms is not None else None),
+                       "tile_map": tile_map_name,
                        "kernel": variant, "seed": KW["seed"]},
             "roofline": {"bound": "fp32_valu", "achieved": kernel_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kernel_tflops / VALU_PEAK_TFLOPS,
                          "traffic": traffic,

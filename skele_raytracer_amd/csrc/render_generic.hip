@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void skr_gactivate_kernel(const RenderParams p
 		}
 		else n.N = normalize3(n.P - ld3(sv.geom[surf])); // :205
 		cn.hits++;
-		n.direct = direct_light_of(sv, p, kd, ld3(ks4), ambp, n.P, n.N, cn);
+		n.direct = direct_light_of<false>(sv, p, kd, ld3(ks4), ambp, n.P, n.N, cn);
 		n.fr = (p.legacy_reflect && !(surf & SURF_TRI)) ? legacy_fresnel(n.d, n.N, ks4.w) : 0.0f; // :46
 		if(p.g_last)
 		{ // its children are shade(depth 0) == (0,0,0): the node is finished

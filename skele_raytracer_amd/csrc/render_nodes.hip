@@ -209,7 +209,7 @@ SKR_DEV Activated activate_record(const SceneView &sv, const RenderParams &p, bo
 		const f3 P = co0 + d * t;
 		a.N = normalize3(P - ld3(sv.geom[a.sph]));
 		cn.hits++;
-		a.direct = direct_light(sv, p, (int) a.sph, P, a.N, cn);
+		a.direct = direct_light<false>(sv, p, (int) a.sph, P, a.N, cn);
 		a.co = add_scalar(P, 0.00001f);
 	}
 	return a;
@@ -349,7 +349,7 @@ SKR_DEV void leaf_batch(const SceneView &sv, const RenderParams &p, Ring &q, flo
 		const f3 P = co_k + d * t;
 		const f3 Nn = normalize3(P - ld3(sv.geom[sph]));
 		cn.hits++;
-		const f3 direct = direct_light(sv, p, sph, P, Nn, cn);
+		const f3 direct = direct_light<false>(sv, p, sph, P, Nn, cn);
 		const f3 total = mk3(0, 0, 0); // (0,0,0) / N with N >= 1 (skr_nodes_supported): +0 in every component, no division needed
 		const f3 colour = (div3_const(direct, SKR_DIV_PI) + total * 2.0f) * ld3(sv.kd[sph]);
 		const f3 c = div3_const(colour * r1, SKR_DIV_PDF);

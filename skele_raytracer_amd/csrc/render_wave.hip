@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void skr_direct_kernel(const RenderParams p)
 				cn.hits++;
 				const f3 P = p.cam_pos + dir * tmin;
 				const f3 N = normalize3(P - ld3(sv.geom[sph]));
-				smp = direct_light(sv, p, sph, P, N, cn);
+				smp = direct_light<true>(sv, p, sph, P, N, cn);
 				if(p.monte_carlo)
 				{ // --gillum at --depth 1: the N children are shade(depth 0) == 0 (:142-145), the combination of :133, :213 stays
 					const f3 total = mk3(0, 0, 0) / (float) p.num_path_traces;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) SKR_PRIMARY_ATTR void skr_primary_kernel(const
 	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
 	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	__syncthreads();
-	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work};
+	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work, SKR_GEOM_SMEM ? p.sph_geom : s_geom};
 
 	const int wave = tid >> 6, lane = tid & 63;
 	const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) SKR_PRIMARY_ATTR void skr_primary_kernel(const
 			cn.hits++;
 			const f3 P = p.cam_pos + dir * tmin;
 			N = normalize3(P - ld3(sv.geom[sph]));
-			colour = direct_light(sv, p, sph, P, N, cn);
+			colour = direct_light<true>(sv, p, sph, P, N, cn);
 			co = add_scalar(P, 0.00001f);
 		}
 	}

@@ -25,7 +25,26 @@ struct SceneView {
 	int chunk;            // triangles per chunk sphere (tri_chunks.h)
 	int cones;            // some entry carries a tight radius for non-grazing rays
 	unsigned long long *tri_work; // HBM, or null (not counting): SKR_TRI_WORK_SHARDS x {culling-sphere tests, triangle tests} the walks executed (lanes that needed them)
+	const float4 *geom_u; // the rows of `geom` for the loops that walk the spheres in order with a wave-uniform index (SKR_GEOM_SMEM: in HBM,
+	                      // read by scalar loads into SGPRs; otherwise the LDS copy)
 };
+#ifndef SKR_GEOM_SMEM
+#define SKR_GEOM_SMEM 0
+#endif
+// row i of sv.geom_u, i wave-uniform.  SKR_GEOM_SMEM: through the constant address space, which is what makes the compiler take the
+// scalar path (s_load_dwordx4 into SGPRs) — through the plain pointer it cannot prove that no store of the kernel aliases the row and
+// issues a vector load with a uniform address.
+typedef float skr_v4f __attribute__((ext_vector_type(4)));
+SKR_DEV float4 geom_row_u(const SceneView &sv, int i)
+{
+#if SKR_GEOM_SMEM
+	const skr_v4f __attribute__((address_space(4))) *q = (const skr_v4f __attribute__((address_space(4))) *) (unsigned long long) sv.geom_u;
+	const skr_v4f v = q[i];
+	return make_float4(v.x, v.y, v.z, v.w);
+#else
+	return sv.geom_u[i];
+#endif
+}
 
 // What a triangle walk executed, counted per wave on the scalar unit (population counts of lane masks the walk forms anyway) and added
 // to one of SKR_TRI_WORK_SHARDS words by one lane when the walk ends: bench.py's FP32-VALU figure for mesh scenes is built from
@@ -232,6 +251,11 @@ SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float t
 
 // utils.h:42-58: any sphere with 1 < t < inf along the (unbounded) shadow ray; two lights at a
 // time, because both shadow rays start at the same point and share e and c per sphere.
+// COHERENT: the lanes of the wave are neighbouring pixels (the direct kernel's 8x8 tiles), where a whole wave in one shadow is common
+// and the loop is left once every lane's rays are occluded.  The level pipelines' lanes are hits from all over the scene: the wave-wide
+// test never fires there and costs a branch and half a dozen instructions per sphere (headline leaf kernel 1.282 -> 1.247 ms without
+// it; two spheres per trip written out by hand, on top: 1.287 ms — eight more live registers, 47 spilled instead of 24).
+template <bool COHERENT>
 SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second, bool &occ0, bool &occ1, uint32_t &tests)
 {
 	const f3 o = add_scalar(P, 0.000001f);
@@ -239,13 +263,8 @@ SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second,
 	const PairAny pa{rp.two_a, rp.two_a * 0.25f, rp.sane0, rp.sane1};
 	occ0 = false;
 	occ1 = !second;
-	float4 g_next = sv.geom[0];
-#pragma unroll 2 // (as in closest_pair_deferred)
-	for(int i = 0; i < sv.ns; i++)
+	auto test = [&](const float4 g, int i)
 	{
-		const float4 g = g_next;
-		g_next = sv.geom[i + 1];
-		__builtin_amdgcn_sched_barrier(0); // (as in closest_pair_deferred)
 		const f3 e = o - ld3(g);
 		const float c = dot3(e, e) - g.w;
 		f2 b, D;
@@ -270,15 +289,16 @@ SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second,
 				occ1 = any_decide(pa.sane1, pa.two_a.y, pa.quarter.y, b.y, D.y, m.y, al.y, rl.y);
 				if(occ1) tests += (uint32_t) i + 1u;
 			}
-#if defined(SKR_DIAG) && SKR_DIAG
-			{
-				const unsigned long long c0 = __ballot(cand0), c1 = __ballot(cand1), o0 = __ballot(cand0 && occ0), o1 = __ballot(cand1 && occ1);
-				DIAG_WAVE(15, __popcll(c0) + __popcll(c1)); // candidate shadow rays
-				DIAG_WAVE(16, __popcll(o0) + __popcll(o1)); // occluded by this sphere
-			}
-#endif
 		}
-		if(__all(occ0 && occ1)) break;
+	};
+	float4 g_next = geom_row_u(sv, 0);
+	for(int i = 0; i < sv.ns; i++)
+	{
+		const float4 g = g_next;
+		g_next = geom_row_u(sv, i + 1);
+		__builtin_amdgcn_sched_barrier(0); // (as in closest_pair_deferred)
+		test(g, i);
+		if(COHERENT && __all(occ0 && occ1)) break;
 	}
 	if(!occ0) tests += (uint32_t) sv.ns;
 	if(second && !occ1) tests += (uint32_t) sv.ns;
@@ -312,6 +332,7 @@ SKR_DEV LightTerm light_term(const SceneView &sv, int i, f3 P)
 // raytrace.h:36-44 = bp::ambient (blinn_phong.h:13) + diffuse (:47) + specular (:90).
 // The reference casts the same shadow ray in diffuse and again in specular; one cast serves both.
 // (kd, ks, ambp = {La * ka, power}: the material rows of the surface hit)
+template <bool COHERENT>
 SKR_DEV f3 direct_light_of(const SceneView &sv, const RenderParams &p, f3 kd, f3 ks, float4 ambp, f3 P, f3 N, Counters &cn)
 {
 	f3 diffuse = mk3(0, 0, 0), specular = mk3(0, 0, 0);
@@ -324,7 +345,7 @@ SKR_DEV f3 direct_light_of(const SceneView &sv, const RenderParams &p, f3 kd, f3
 		if(p.use_shadows)
 		{
 			cn.shadow_rays += second ? 2u : 1u;
-			occluded_pair(sv, P, t0.L, t1.L, second, occ0, occ1, cn.shadow_tests);
+			occluded_pair<COHERENT>(sv, P, t0.L, t1.L, second, occ0, occ1, cn.shadow_tests);
 		}
 		auto add_light = [&](const LightTerm &t, bool lit)
 		{
@@ -346,9 +367,10 @@ SKR_DEV f3 direct_light_of(const SceneView &sv, const RenderParams &p, f3 kd, f3
 	return total;
 }
 
+template <bool COHERENT>
 SKR_DEV f3 direct_light(const SceneView &sv, const RenderParams &p, int sph, f3 P, f3 N, Counters &cn)
 {
-	return direct_light_of(sv, p, ld3(sv.kd[sph]), ld3(sv.ks[sph]), sv.amb[sph], P, N, cn);
+	return direct_light_of<COHERENT>(sv, p, ld3(sv.kd[sph]), ld3(sv.ks[sph]), sv.amb[sph], P, N, cn);
 }
 
 // raytrace.h:22-30 + :117-125: hemisphere sample and the reference's basis mix

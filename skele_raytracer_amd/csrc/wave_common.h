@@ -79,12 +79,12 @@ SKR_DEV void closest_pair_deferred(const SceneView &sv, f3 o, f3 d0, f3 d1, bool
 {
 	s0 = BestState{-1, __builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f, 0.0f};
 	s1 = s0;
-	float4 g_next = sv.geom[0];
-#pragma unroll 2 // two spheres per trip: the prefetched sphere needs no register-to-register copy (3 of the 24 instructions of a trip)
+	float4 g_next = geom_row_u(sv, 0);
+	// (one sphere per trip: `#pragma unroll 2` is ignored for a run-time trip count, and two per trip written out by hand cost more in registers than the copies save)
 	for(int i = 0; i < sv.ns; i++)
 	{
 		const float4 g = g_next;
-		g_next = sv.geom[i + 1];
+		g_next = geom_row_u(sv, i + 1);
 		__builtin_amdgcn_sched_barrier(0); // the prefetch is issued here, a whole trip ahead of its use, not behind the arithmetic
 		const f3 e = o - ld3(g);
 		const float c = dot3(e, e) - g.w;
@@ -205,7 +205,7 @@ SKR_DEV SceneView stage_scene(const RenderParams &p, float4 *lds4, bool tris)
 	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
 	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	__syncthreads();
-	return SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, tris ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work};
+	return SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, tris ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work, SKR_GEOM_SMEM ? p.sph_geom : s_geom};
 }
 
 SKR_DEV void add_counters(const RenderParams &p, const Counters &cn, uint32_t shard, int lane)
