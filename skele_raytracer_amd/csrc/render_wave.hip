@@ -239,14 +239,15 @@ __global__ __launch_bounds__(256) void skr_resolve_kernel(const RenderParams p)
 	}
 }
 
-// the direct kernel's workgroup: the scene + 4 x 192 bytes of tile — and, for meshes, padding up to a third of the CU's LDS: the
-// triangle walk of dragon.scn runs 2.05 / 1.31 / 1.28 / 1.36 ms at 1 / 2 / 3 / 4+ waves per SIMD (measured), spheres2 --jsample 5
-// 1.83 / 1.63 ms at 3 / 4+
+// the direct kernel's workgroup: the scene + 4 x 192 bytes of tile — and, for a scene that is all mesh (every lane's time is the triangle
+// walk, whose scalar loads go through a 16 KB cache that more waves only thrash), padding up to a third of the CU's LDS: dragon.scn
+// runs 1.18 / 1.24 / 1.26 ms at 3 / 4 / 5 waves per SIMD.  A mesh among spheres wants the fourth wave to hide the shading's latencies:
+// test.scn (1800 triangles, 4 spheres) 0.556 / 0.485 ms at 3 / 4.
 size_t skr_wave_lds_bytes(const RenderParams &p)
 {
 	const size_t need = ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 4 * 192;
 	const size_t third = 53248; // 3 x 53 248 B are co-resident on a CU (1280-byte granules), 4 are not
-	return (p.n_tris > 0 && need < third) ? third : need;
+	return (p.n_tris > 0 && p.n_spheres == 0 && need < third) ? third : need;
 }
 
 // one launch, no tree: any scene the LDS holds

@@ -35,14 +35,34 @@ struct SceneView {
 // scalar path (s_load_dwordx4 into SGPRs) — through the plain pointer it cannot prove that no store of the kernel aliases the row and
 // issues a vector load with a uniform address.
 typedef float skr_v4f __attribute__((ext_vector_type(4)));
+SKR_DEV float4 load_const4(const float4 *base, int i)
+{
+	const skr_v4f __attribute__((address_space(4))) *q = (const skr_v4f __attribute__((address_space(4))) *) (unsigned long long) base;
+	const skr_v4f v = q[i];
+	return make_float4(v.x, v.y, v.z, v.w);
+}
 SKR_DEV float4 geom_row_u(const SceneView &sv, int i)
 {
 #if SKR_GEOM_SMEM
-	const skr_v4f __attribute__((address_space(4))) *q = (const skr_v4f __attribute__((address_space(4))) *) (unsigned long long) sv.geom_u;
-	const skr_v4f v = q[i];
-	return make_float4(v.x, v.y, v.z, v.w);
+	return load_const4(sv.geom_u, i);
 #else
 	return sv.geom_u[i];
+#endif
+}
+// Row i of the mesh tables (triangles, culling data: HBM, never written by a kernel), i wave-uniform: one s_load_dwordx4 into SGPRs.
+// Through the plain pointer the compiler issues a VECTOR load with a uniform address (it cannot prove that no store of the kernel
+// aliases the table): 26 M vector-memory instructions per dragon frame, found in the round-3 counters (SQ_INSTS_VMEM against
+// SQ_INSTS_SMEM = 0.5 M) under a comment that said "scalar loads".  Through the constant address space: dragon.scn 1080p 1.306 ->
+// 1.18 ms, with --shade-triangles 2.99 -> 2.10 ms; test.scn 640x360 --gillum 4 (a dozen triangles, incoherent lanes) 1.10 -> 1.16 ms.
+#ifndef SKR_MESH_SMEM
+#define SKR_MESH_SMEM 1
+#endif
+SKR_DEV float4 mesh_row(const float4 *base, int i)
+{
+#if SKR_MESH_SMEM
+	return load_const4(base, i);
+#else
+	return base[i];
 #endif
 }
 
@@ -161,7 +181,7 @@ SKR_DEV bool line_touches(const RayConst &r, float dd, float4 A, float4 B)
 
 // A line that misses a conservative sphere cannot pass the test for any triangle below it, so a node or chunk that
 // no lane's line touches is skipped whole.  The levels above the chunks are stored depth-first with skip links:
-// one wave-uniform index, no stack; both possible successors are fetched (scalar loads) while the sphere is tested.
+// one wave-uniform index, no stack; both possible successors are fetched (scalar loads: mesh_row) while the sphere is tested.
 template <bool CONES, bool COUNT>
 SKR_DEV bool tree_walk(const SceneView &sv, const RayConst &r, float tmin)
 {
@@ -170,37 +190,37 @@ SKR_DEV bool tree_walk(const SceneView &sv, const RayConst &r, float tmin)
 	int i = 0;
 	uint32_t n_cull = 0, n_tri = 0; // (wave-uniform: scalar registers)
 	const float4 *chunk_ent = sv.chunks + 3 * (sv.nchunks + 1); // behind the nodes and their pad
-	float4 A = sv.chunks[0], B = sv.chunks[1], lk = sv.chunks[2];
+	float4 A = mesh_row(sv.chunks, 0), B = mesh_row(sv.chunks, 1), lk = mesh_row(sv.chunks, 2);
 	while(i < sv.nchunks)
 	{
 		const int i_out = __float_as_int(lk.x);
 		// first child (or the next node after a height-1 node) and next sibling (padded past the end)
-		const float4 A_in = sv.chunks[3 * i + 3], B_in = sv.chunks[3 * i + 4], lk_in = sv.chunks[3 * i + 5];
-		const float4 A_out = sv.chunks[3 * i_out], B_out = sv.chunks[3 * i_out + 1], lk_out = sv.chunks[3 * i_out + 2];
+		const float4 A_in = mesh_row(sv.chunks, 3 * i + 3), B_in = mesh_row(sv.chunks, 3 * i + 4), lk_in = mesh_row(sv.chunks, 3 * i + 5);
+		const float4 A_out = mesh_row(sv.chunks, 3 * i_out), B_out = mesh_row(sv.chunks, 3 * i_out + 1), lk_out = mesh_row(sv.chunks, 3 * i_out + 2);
 		if(COUNT) n_cull += (uint32_t) __popcll(__ballot(!hit));
 		const bool enter = __any(!hit && line_touches<CONES>(r, dd, A, B));
 		const int count = __float_as_int(lk.z);
 		if(enter && count > 0)
 		{ // height 1: its chunk entries are contiguous — tight loop, next entry prefetched
 			const int c0 = __float_as_int(lk.y), c1 = c0 + count;
-			float4 cA_next = chunk_ent[2 * c0], cB_next = chunk_ent[2 * c0 + 1];
+			float4 cA_next = mesh_row(chunk_ent, 2 * c0), cB_next = mesh_row(chunk_ent, 2 * c0 + 1);
 			for(int c = c0; c < c1; c++)
 			{
 				const float4 cA = cA_next, cB = cB_next;
-				cA_next = chunk_ent[2 * c + 2];
-				cB_next = chunk_ent[2 * c + 3];
+				cA_next = mesh_row(chunk_ent, 2 * c + 2);
+				cB_next = mesh_row(chunk_ent, 2 * c + 3);
 				if(COUNT) n_cull += (uint32_t) __popcll(__ballot(!hit));
 				const bool mine = !hit && line_touches<CONES>(r, dd, cA, cB);
 				if(__any(mine))
 				{
 					const int i0 = c * sv.chunk, i1 = (i0 + sv.chunk < sv.nt) ? i0 + sv.chunk : sv.nt;
-					float4 n0 = sv.tris[3 * i0], n1 = sv.tris[3 * i0 + 1], n2 = sv.tris[3 * i0 + 2];
+					float4 n0 = mesh_row(sv.tris, 3 * i0), n1 = mesh_row(sv.tris, 3 * i0 + 1), n2 = mesh_row(sv.tris, 3 * i0 + 2);
 					for(int k = i0; k < i1; k++)
 					{
 						const f3 v0 = ld3(n0), e1 = ld3(n1), e2 = ld3(n2);
-						n0 = sv.tris[3 * k + 3];
-						n1 = sv.tris[3 * k + 4];
-						n2 = sv.tris[3 * k + 5];
+						n0 = mesh_row(sv.tris, 3 * k + 3);
+						n1 = mesh_row(sv.tris, 3 * k + 4);
+						n2 = mesh_row(sv.tris, 3 * k + 5);
 						float t;
 						if(COUNT) n_tri += (uint32_t) __popcll(__ballot(mine && !hit));
 						if(mine && !hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
@@ -233,13 +253,13 @@ SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float t
 	uint32_t n_tri = 0;
 	// wave-uniform addresses => scalar loads; triangle i+1 is fetched while i is tested
 	// (tris[] carries one pad triangle so the prefetch needs no bounds test)
-	float4 n0 = sv.tris[0], n1 = sv.tris[1], n2 = sv.tris[2];
+	float4 n0 = mesh_row(sv.tris, 0), n1 = mesh_row(sv.tris, 1), n2 = mesh_row(sv.tris, 2);
 	for(int i = 0; i < sv.nt; i++)
 	{
 		const f3 v0 = ld3(n0), e1 = ld3(n1), e2 = ld3(n2);
-		n0 = sv.tris[3 * i + 3];
-		n1 = sv.tris[3 * i + 4];
-		n2 = sv.tris[3 * i + 5];
+		n0 = mesh_row(sv.tris, 3 * i + 3);
+		n1 = mesh_row(sv.tris, 3 * i + 4);
+		n2 = mesh_row(sv.tris, 3 * i + 5);
 		float t;
 		if(sv.tri_work) n_tri += (uint32_t) __popcll(__ballot(!hit));
 		if(!hit && triangle_hit(r.o, r.d, v0, e1, e2, t) && t < tmin) hit = true;
@@ -459,12 +479,12 @@ SKR_DEV void tree_walk_closest(const SceneView &sv, const RayConst &r, int from_
 	int i = 0;
 	uint32_t n_cull = 0, n_tri = 0;
 	const float4 *chunk_ent = sv.chunks + 3 * (sv.nchunks + 1);
-	float4 A = sv.chunks[0], B = sv.chunks[1], lk = sv.chunks[2];
+	float4 A = mesh_row(sv.chunks, 0), B = mesh_row(sv.chunks, 1), lk = mesh_row(sv.chunks, 2);
 	while(i < sv.nchunks)
 	{
 		const int i_out = __float_as_int(lk.x);
-		const float4 A_in = sv.chunks[3 * i + 3], B_in = sv.chunks[3 * i + 4], lk_in = sv.chunks[3 * i + 5];
-		const float4 A_out = sv.chunks[3 * i_out], B_out = sv.chunks[3 * i_out + 1], lk_out = sv.chunks[3 * i_out + 2];
+		const float4 A_in = mesh_row(sv.chunks, 3 * i + 3), B_in = mesh_row(sv.chunks, 3 * i + 4), lk_in = mesh_row(sv.chunks, 3 * i + 5);
+		const float4 A_out = mesh_row(sv.chunks, 3 * i_out), B_out = mesh_row(sv.chunks, 3 * i_out + 1), lk_out = mesh_row(sv.chunks, 3 * i_out + 2);
 		if(sv.tri_work) n_cull += (uint32_t) __popcll(__ballot(true));
 		const bool enter = __any(entry_may_hold_nearer<CONES>(r, dd, A, B, b.t));
 		const int count = __float_as_int(lk.z);
@@ -474,12 +494,12 @@ SKR_DEV void tree_walk_closest(const SceneView &sv, const RayConst &r, int from_
 			for(int c = c0; c < c1; c++)
 			{
 				if(sv.tri_work) n_cull += (uint32_t) __popcll(__ballot(true));
-				const bool mine = entry_may_hold_nearer<CONES>(r, dd, chunk_ent[2 * c], chunk_ent[2 * c + 1], b.t);
+				const bool mine = entry_may_hold_nearer<CONES>(r, dd, mesh_row(chunk_ent, 2 * c), mesh_row(chunk_ent, 2 * c + 1), b.t);
 				if(__any(mine))
 				{
 					const int i0 = c * sv.chunk, i1 = (i0 + sv.chunk < sv.nt) ? i0 + sv.chunk : sv.nt;
 					if(sv.tri_work) n_tri += (uint32_t) __popcll(__ballot(mine)) * (uint32_t) (i1 - i0);
-					for(int k = i0; k < i1; k++) tri_consider(r, mine, ld3(sv.tris[3 * k]), sv.tris[3 * k + 1], sv.tris[3 * k + 2], k, from_tri, b);
+					for(int k = i0; k < i1; k++) tri_consider(r, mine, ld3(mesh_row(sv.tris, 3 * k)), mesh_row(sv.tris, 3 * k + 1), mesh_row(sv.tris, 3 * k + 2), k, from_tri, b);
 				}
 			}
 		}
@@ -499,7 +519,7 @@ SKR_DEV void closest_triangle(const SceneView &sv, const RayConst &r, int from_t
 		else tree_walk_closest<false>(sv, r, from_tri, b);
 		return;
 	}
-	for(int k = 0; k < sv.nt; k++) tri_consider(r, true, ld3(sv.tris[3 * k]), sv.tris[3 * k + 1], sv.tris[3 * k + 2], k, from_tri, b);
+	for(int k = 0; k < sv.nt; k++) tri_consider(r, true, ld3(mesh_row(sv.tris, 3 * k)), mesh_row(sv.tris, 3 * k + 1), mesh_row(sv.tris, 3 * k + 2), k, from_tri, b);
 }
 
 // ---- --legacy-reflect: the leaf functions of raytrace.h:45-103 ----
