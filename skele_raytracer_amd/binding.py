@@ -181,7 +181,10 @@ class Scene:
 
     def close(self):
         if self.h:
-            lib().skr_scene_destroy(self.h)
+            try:
+                lib().skr_scene_destroy(self.h)
+            except TypeError:  # (interpreter teardown)
+                pass
             self.h = None
 
     __del__ = close
@@ -287,7 +290,10 @@ class Renderer:
 
     def close(self):
         if getattr(self, "h", None):
-            lib().skr_renderer_destroy(self.h)
+            try:
+                lib().skr_renderer_destroy(self.h)
+            except TypeError:  # interpreter teardown: the module's globals are gone, the process is about to free everything
+                pass
             self.h = None
 
     __del__ = close
@@ -439,7 +445,10 @@ class Comm:
 
     def close(self):
         if getattr(self, "h", None):
-            lib().skr_comm_destroy(self.h)
+            try:
+                lib().skr_comm_destroy(self.h)
+            except TypeError:  # (interpreter teardown)
+                pass
             self.h = None
 
     __del__ = close
@@ -482,7 +491,10 @@ class Multi:
 
     def close(self):
         if getattr(self, "h", None):
-            lib().skr_multi_destroy(self.h)
+            try:
+                lib().skr_multi_destroy(self.h)
+            except TypeError:  # (interpreter teardown)
+                pass
             self.h = None
 
     __del__ = close

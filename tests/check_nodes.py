@@ -54,7 +54,7 @@ for k in ("SKR_UNIT_HALF", "SKR_LEVELS_BUDGET_MB", "SKR_PIPELINE"): os.environ.p
 print("failures:", bad, flush=True)
 
 def timeit(scn, w, h, reps, env, **kw):
-    for k in ("SKR_UNIT_HALF", "SKR_PIPELINE", "SKR_KERNEL"): os.environ.pop(k, None)
+    for k in ("SKR_UNIT_HALF", "SKR_PIPELINE", "SKR_FLAT"): os.environ.pop(k, None)
     os.environ.update(env)
     r = renderer(scn); opt = skr.Options(w, h, **kw)
     buf = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda"); st = torch.cuda.current_stream()
@@ -69,25 +69,15 @@ def timeit(scn, w, h, reps, env, **kw):
 
 if "--time" in sys.argv:
     H = dict(gillum=16, shadow=True, seed=20261004)
-    OLD3, OLD2 = {"SKR_PIPELINE": "levels"}, {"SKR_PIPELINE": "queue"}
-    for _ in range(2):
-        timeit("spheres2.scn", 1920, 1080, 20, OLD3, **H)
-        timeit("spheres2.scn", 1920, 1080, 20, {}, **H)
-    timeit("spheres2.scn", 1920, 1080, 10, OLD2, gillum=16, shadow=True, depth=2, seed=20261004)
-    timeit("spheres2.scn", 1920, 1080, 10, {}, gillum=16, shadow=True, depth=2, seed=20261004)
-    timeit("spheres2.scn", 1920, 1080, 10, OLD3, gillum=16, seed=20261004)
-    timeit("spheres2.scn", 1920, 1080, 10, {}, gillum=16, seed=20261004)
-    timeit("bear.scn", 1920, 1080, 10, OLD3, gillum=16, shadow=True, seed=3)
-    timeit("bear.scn", 1920, 1080, 10, {}, gillum=16, shadow=True, seed=3)
-    timeit("spheres1.scn", 1920, 1080, 10, OLD3, gillum=16, shadow=True, seed=3)
-    timeit("spheres1.scn", 1920, 1080, 10, {}, gillum=16, shadow=True, seed=3)
-    timeit("spheres2.scn", 960, 540, 3, OLD3, gillum=64, shadow=True, seed=5)
+    FLAT, PERS, GEN = {"SKR_FLAT": "1"}, {"SKR_FLAT": "0"}, {"SKR_PIPELINE": "generic"}
+    for env in ({}, FLAT, GEN):
+        timeit("spheres2.scn", 1920, 1080, 20, env, **H)
+    for env in ({}, PERS, GEN):
+        timeit("spheres2.scn", 1920, 1080, 10, env, gillum=16, shadow=True, depth=2, seed=20261004)
+        timeit("bear.scn", 1920, 1080, 10, env, gillum=16, shadow=True, seed=3)
+        timeit("spheres2.scn", 480, 270, 2, env, gillum=4, depth=4, shadow=True, seed=5)
     timeit("spheres2.scn", 960, 540, 3, {}, gillum=64, shadow=True, seed=5)
-    timeit("spheres2.scn", 1920, 1080, 5, OLD3, gillum=4, shadow=True, seed=5)
-    timeit("spheres2.scn", 1920, 1080, 5, {}, gillum=4, shadow=True, seed=5)
-    timeit("spheres2.scn", 480, 270, 2, {"SKR_PIPELINE": "mega", "SKR_KERNEL": "v1"}, gillum=4, depth=4, shadow=True, seed=5)
-    os.environ.pop("SKR_KERNEL", None)
-    timeit("spheres2.scn", 480, 270, 2, {}, gillum=4, depth=4, shadow=True, seed=5)
-    timeit("test.scn", 640, 360, 2, OLD2, gillum=4, shadow=True)
+    timeit("test.scn", 640, 360, 2, {}, gillum=4, shadow=True)
     timeit("test.scn", 640, 360, 2, {"SKR_PIPELINE": "nodes"}, gillum=4, shadow=True)
+    for k in ("SKR_FLAT", "SKR_PIPELINE"): os.environ.pop(k, None)
 sys.exit(1 if bad else 0)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle campaign (development aid; the committed tests hold fixed cases): random sphere / mesh scenes, random
-options over every mode the product has (--gillum at random N and depth through both schedules of the node pipeline, --jsample,
---shadow, --strict-scn, --shade-triangles, --legacy-reflect, --progressive), small frames, bit-for-bit comparison of the float image,
+options over every mode the product has (--gillum at random N and depth through both schedules of the node pipeline and through the
+general level pipeline, --jsample, --shadow, --strict-scn, --shade-triangles, --legacy-reflect — also together, at any depth —,
+--progressive), small frames, bit-for-bit comparison of the float image,
 the bytes and the ray / hit / shadow-ray counts.
 
     python tests/fuzz_parity.py [cases=200] [seed=1]
@@ -55,12 +56,13 @@ def main():
             while n ** (d - 1) * w * h > 3e6:
                 d -= 1
             kw.update(gillum=n, depth=max(d, 1))
-        if mode in ("legacy", "surfaces") and kw.get("depth", 3) > 4:
-            kw["depth"] = 4
         if mode == "legacy":
             kw.update(legacy_reflect=True)
-            if "gillum" in kw and kw["depth"] > 3:
-                kw["depth"] = 3
+            if rng.random() < .3:
+                kw.update(shade_triangles=True)
+            # (the tree has N + 2 L children per node: keep the frame small)
+            while kw.get("depth", 3) > 2 and (kw.get("gillum", 0) + 8) ** (kw.get("depth", 3) - 1) * w * h > 3e6:
+                kw["depth"] = kw.get("depth", 3) - 1
         if mode == "surfaces":
             kw.update(shade_triangles=True)
         if rng.random() < .25:
@@ -71,7 +73,9 @@ def main():
             env["SKR_FLAT"] = "0"
         if "gillum" in kw and rng.random() < .2:
             env["SKR_LEVELS_BUDGET_MB"] = str(int(rng.choice([8, 16, 64])))
-        for k in ("SKR_FLAT", "SKR_LEVELS_BUDGET_MB"):
+        if mode == "gi" and "gillum" in kw and rng.random() < .25:
+            env["SKR_PIPELINE"] = "generic"
+        for k in ("SKR_FLAT", "SKR_LEVELS_BUDGET_MB", "SKR_PIPELINE"):
             os.environ.pop(k, None)
         os.environ.update(env)
         try:

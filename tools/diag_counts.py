@@ -11,12 +11,12 @@ from skele_raytracer_amd import binding
 r = skr.Renderer(skr.parse_scene(os.path.join(ROOT, "tests/golden/scenes/spheres2.scn")))
 opt = skr.Options(1920, 1080, gillum=16, shadow=True, seed=20261004)
 L = binding.lib()
-out, out2 = np.zeros(32, np.uint64), np.zeros(32, np.uint64)
+out = np.zeros(32, np.uint64)
 r.render(opt); torch.cuda.synchronize()
-L.skr_diag_read(C.c_void_p(out.ctypes.data), 1); L.skr_diag_read_nodes(C.c_void_p(out2.ctypes.data), 1)
+L.skr_diag_read_nodes(C.c_void_p(out.ctypes.data), 1)
 r.render(opt); torch.cuda.synchronize()
-L.skr_diag_read(C.c_void_p(out.ctypes.data), 1); L.skr_diag_read_nodes(C.c_void_p(out2.ctypes.data), 1)
-out = out + out2  # the counters live once per translation unit (render_wave.hip, render_nodes.hip)
+L.skr_diag_read_nodes(C.c_void_p(out.ctypes.data), 1)
+# (the counters of render_nodes.hip's translation unit: the trace, leaf and finalize kernels of the node pipeline)
 names = ["closest-pair iterations", "closest-pair candidate paths", "  lanes in them", "exact-root fallbacks (lanes)", "shadow-pair iterations", "shadow candidate paths",
          "  lanes in them", "exact-root fallbacks (wave events)", "bracket overlaps -> exact loop (wave events)", "leaf shading batches", "  hits in them",
          "activation batches", "  records in them", "closest-pair candidate RAYS", "  accepted", "shadow candidate RAYS", "  occluders found", "  closest-pair candidates a t2 <= 1 pre-test rejects", "  closest-pair candidate paths left with it"] + ["counter %d" % i for i in range(19, 32)]
