@@ -304,7 +304,11 @@ static int render_pass(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	// (--shade-triangles: a triangle hit recurses too)
 	p.shade_triangles = (opt->shade_triangles && p.n_tris > 0) ? 1 : 0;
 	p.tri_mats = r->d_blob + r->off_tri_mats;
-	p.legacy_reflect = (opt->legacy_reflect && p.n_spheres > 0) ? 1 : 0; // (only a sphere hit has the terms of raytrace.h:45-103)
+	// Only a sphere hit has the terms of raytrace.h:45-103, so a scene without spheres has nothing to add — but the flag also sets the
+	// arity of the counter RNG's node ids (N + 2 L, include/skr.h), and a tree over triangle surfaces (--shade-triangles --gillum) has
+	// nodes whatever the scene holds: there the flag stays, the legacy children simply never exist (found by tests/fuzz_parity.py:
+	// with the flag folded away the node ids from the fourth level down were numbered with arity N)
+	p.legacy_reflect = (opt->legacy_reflect && (p.n_spheres > 0 || p.shade_triangles)) ? 1 : 0;
 	if(!p.legacy_reflect && (!p.monte_carlo || (p.n_spheres == 0 && !p.shade_triangles) || p.num_path_traces == 0)) p.max_depth = 1;
 	if(p.max_depth > 1)
 	{ // tree node ids are 32-bit RNG counter words: need N^(depth-1) < 2^32

@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256, SKR_LEAF2_OCC) void skr_leaf_kernel2(const Ren
 			else
 			{
 				direct = direct1;
-				const float4 r1row = p.rc[out_idx];
+				const float4 r1row = p.rc[out_idx]; // (asked for here, behind the window sums: asking earlier was measured and changes nothing, 1.570 / 1.569 ms)
 				r1 = r1row.z;
 				sph = __float_as_uint(r1row.y) & 0xffffu;
 			}

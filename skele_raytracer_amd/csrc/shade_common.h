@@ -214,6 +214,8 @@ SKR_DEV bool tree_walk(const SceneView &sv, const RayConst &r, float tmin)
 				if(__any(mine))
 				{
 					const int i0 = c * sv.chunk, i1 = (i0 + sv.chunk < sv.nt) ? i0 + sv.chunk : sv.nt;
+					// (one triangle per scalar-cache round trip, the next one asked for meanwhile; a whole 4-triangle chunk asked for at once was measured
+					// slower: dragon 1.19 -> 1.27 ms, 48 more SGPRs live)
 					float4 n0 = mesh_row(sv.tris, 3 * i0), n1 = mesh_row(sv.tris, 3 * i0 + 1), n2 = mesh_row(sv.tris, 3 * i0 + 2);
 					for(int k = i0; k < i1; k++)
 					{

@@ -36,12 +36,9 @@ def write_sphere_scene(path, rng):
     open(path, "w").write("\n".join(lines) + "\n")
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    tmp = tempfile.mkdtemp()
-    bad = 0
-    seen = {}
+def generate(rng, cases, tmp):
+    """The campaign's cases, in order: (index, scene file, width, height, option keywords, strict, passes, environment switches).
+    The draws do not depend on any render, so a case can be replayed by its index (FUZZ_ONLY)."""
     for c in range(cases):
         scn = os.path.join(tmp, "s%d.scn" % c)
         mesh = rng.random() < 0.35
@@ -75,9 +72,23 @@ def main():
             env["SKR_LEVELS_BUDGET_MB"] = str(int(rng.choice([8, 16, 64])))
         if mode == "gi" and "gillum" in kw and rng.random() < .25:
             env["SKR_PIPELINE"] = "generic"
+
+        yield c, scn, w, h, kw, strict, passes, env
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    tmp = tempfile.mkdtemp()
+    bad = 0
+    seen = {}
+    ONLY = int(os.environ["FUZZ_ONLY"]) if os.environ.get("FUZZ_ONLY") else None  # replay one case of a campaign
+    for c, scn, w, h, kw, strict, passes, env in generate(rng, cases, tmp):
         for k in ("SKR_FLAT", "SKR_LEVELS_BUDGET_MB", "SKR_PIPELINE"):
             os.environ.pop(k, None)
         os.environ.update(env)
+        if ONLY is not None and c != ONLY:
+            continue
         try:
             r = skr.Renderer(skr.parse_scene(scn, strict=strict))
             rgb, rgbf = r.render(skr.Options(w, h, progressive=passes, **kw), want_float=True)
@@ -93,7 +104,9 @@ def main():
             counts = cnt["radiance_rays"] == int(st[0]) and cnt["sphere_hits"] == int(st[1]) and (not kw.get("shadow") or cnt["shadow_rays"] == int(st[2]))
             if not (same and counts):
                 bad += 1
-                print("MISMATCH case %d: %s %dx%d %s strict=%s passes=%d env=%s variant=%s same=%s counts=%s" % (c, scn, w, h, kw, strict, passes, env, r.kernel_variant(), same, counts), flush=True)
+                print("MISMATCH case %d: %s %dx%d %s strict=%s passes=%d env=%s variant=%s same=%s counts=%s device %s oracle %s" % (c, scn, w, h, kw, strict, passes, env, r.kernel_variant(), same, counts, dict(cnt), [int(v) for v in st[:4]]), flush=True)
+                if ONLY is not None:
+                    print(open(scn).read(), flush=True)
         except skr.SkrError as e:
             print("case %d refused (%s): %s" % (c, kw, str(e)[:100]), flush=True)
         if c % 25 == 24:

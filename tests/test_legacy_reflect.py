@@ -133,6 +133,24 @@ def test_gpu_matches_the_oracle_bit_for_bit(gpu, oracle, name, scn, w, h, kw):
 
 
 @pytest.mark.gpu
+def test_a_mesh_without_spheres_keeps_the_node_numbering(gpu, oracle):
+    """The flag sets the arity of the counter RNG's node ids (N + 2 L) even where no hit can have the legacy terms: a scene of triangle
+    surfaces only, under --shade-triangles --gillum.  From the fourth level down the ids differ from arity N's, so the frame does
+    (found by tests/fuzz_parity.py as a count mismatch on a scene too dark to show it)."""
+    scn, w, h = scene_path("dragon.scn"), 40, 23
+    kw = dict(gillum=2, depth=5, shadow=True, seed=9, shade_triangles=True)
+    r = skr.Renderer(skr.parse_scene(scn, strict=True))  # (--strict-scn: the scene's one light is directional)
+    rgb, rgbf = r.render(skr.Options(w, h, legacy_reflect=True, **kw), want_float=True)
+    gpu.cuda.synchronize()
+    cnt = r.counters()
+    o_rgb, o_f, st = oracle.render(scn, w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, legacy_reflect=True, strict=True, **kw)
+    assert int((rgbf.cpu().numpy().view(np.uint32) != o_f.view(np.uint32)).sum()) == 0 and (rgb.cpu().numpy() == o_rgb).all()
+    assert (cnt["radiance_rays"], cnt["sphere_hits"], cnt["shadow_rays"]) == tuple(int(v) for v in st[:3])
+    _, o_plain, st_plain = oracle.render(scn, w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, strict=True, **kw)
+    assert (o_plain.view(np.uint32) != o_f.view(np.uint32)).any()  # (the numbering matters on this scene)
+
+
+@pytest.mark.gpu
 def test_full_size_frame_against_the_readme_picture(gpu):
     """The picture's own command line as far as it is known (spheres2.scn, 1920x1080, --jsample 5, shadows), on the device."""
     ref = readme_picture()
