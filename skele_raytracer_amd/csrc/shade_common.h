@@ -161,6 +161,44 @@ SKR_DEV int closest_sphere(const SceneView &sv, const RayConst &r, float &tmin)
 	return best;
 }
 
+// closest_sphere() for rays that all start at ONE point (the camera: main.cpp:140-182), with e = o - C and c = e.e - r^2 of utils.h:115-118
+// formed once per sphere for the whole workgroup (ec[i] = {e.xyz, c}: the same subtractions, products and sums in the same order, so the same
+// floats) instead of once per ray: 9 of the ~17 instructions a sphere costs a ray.
+SKR_DEV int closest_sphere_from(const SceneView &sv, const float4 *ec, const RayConst &r, float &tmin)
+{
+	const RayFilt f = make_filt(r.d);
+	int best = -1;
+	float best_lo = __builtin_inff(), best_hi = __builtin_inff(), others_lo = __builtin_inff();
+	float best_b = 0.0f, best_D = 0.0f;
+	float4 q_next = ec[0];
+	for(int i = 0; i < sv.ns; i++)
+	{
+		const float4 q = q_next;
+		q_next = ec[i + 1]; // (one pad entry, like geom[])
+		float lo, hi, b, D;
+		if(bracket_from_ec(ld3(q), q.w, r.d, f, lo, hi, b, D))
+		{
+			if(hi < best_hi)
+			{
+				others_lo = __builtin_fminf(others_lo, best_lo);
+				best_lo = lo;
+				best_hi = hi;
+				best = i;
+				best_b = b;
+				best_D = D;
+			}
+			else others_lo = __builtin_fminf(others_lo, lo);
+		}
+	}
+	tmin = __builtin_inff();
+	if(best >= 0)
+	{
+		if(others_lo > best_hi) tmin = (best_lo == best_hi) ? best_lo : near_root_exact(f.two_a, best_b, best_D);
+		else best = closest_sphere_exact(sv, r, tmin);
+	}
+	return best;
+}
+
 // The conservative line-sphere test of the culling data (scene_host.cpp build_triangle_chunks): false only where
 // no triangle below the entry can accept this lane's line.  A = {centre, R^2}; B = {axis / kappa, R_tight^2}: a ray
 // that is not grazing for the entry's (nearly coplanar) triangles, (d . axis / kappa)^2 >= d . d, is held to the

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Development aid: random FULL-SIZE frames (the persistent schedule of the node pipeline, several bands where the tables ask for them)
-on the device, a few rows of each against the oracle, bit for bit.    python tests/check_large.py [cases=12] [seed=1]"""
+"""Development aid: random FULL-SIZE frames (the persistent schedule of the node pipeline, the general level pipeline on meshes and in
+the two opt-in modes, the direct kernel; several bands where the tables ask for them) on the device, a few rows of each against the oracle, bit for bit.    python tests/check_large.py [cases=12] [seed=1]"""
 import os
 import sys
 
@@ -16,11 +16,24 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for c in range(cases):
-    scn = os.path.join(ROOT, "tests/golden/scenes", str(rng.choice(["spheres2.scn", "spheres2.scn", "bear.scn", "spheres1.scn", "test.scn"])))
+    mode = str(rng.choice(["gi", "gi", "gi", "gi", "legacy", "surfaces", "plain"]))
+    scenes = {"gi": ["spheres2.scn", "spheres2.scn", "bear.scn", "spheres1.scn", "test.scn"], "legacy": ["spheres2.scn", "bear.scn", "spheres1.scn", "test.scn"],
+              "surfaces": ["dragon.scn", "test.scn", "spheres1.scn"], "plain": ["spheres2.scn", "dragon.scn", "test.scn", "bear.scn"]}[mode]
+    scn = os.path.join(ROOT, "tests/golden/scenes", str(rng.choice(scenes)))
     w, h = (1920, 1080) if rng.random() < .6 else (int(rng.integers(900, 2600)), int(rng.integers(500, 1500)))
     n = int(rng.choice([2, 3, 5, 8, 16]))
     d = int(rng.choice([2, 3, 3, 4])) if n <= 5 else int(rng.choice([2, 3]))
     kw = dict(gillum=n, depth=d, shadow=bool(rng.random() < .7), seed=int(rng.integers(1, 2 ** 32)))
+    if mode == "legacy":  # (arity N + 2 L: keep the tree small)
+        kw = dict(legacy_reflect=True, depth=int(rng.choice([2, 3, 4])), shadow=kw["shadow"], seed=kw["seed"])
+        if rng.random() < .4:
+            kw.update(gillum=int(rng.choice([1, 2])), depth=min(kw["depth"], 3))
+    if mode == "surfaces":
+        kw = dict(shade_triangles=True, shadow=kw["shadow"], seed=kw["seed"])
+        if rng.random() < .6:
+            kw.update(gillum=int(rng.choice([1, 2, 4])), depth=int(rng.choice([2, 3])))
+    if mode == "plain":
+        kw = dict(shadow=kw["shadow"], seed=kw["seed"], jsample=int(rng.choice([0, 2, 3])))
     strict = bool(rng.random() < .3)
     r = skr.Renderer(skr.parse_scene(scn, strict=strict))
     rgb, rgbf = r.render(skr.Options(w, h, **kw), want_float=True)
