@@ -215,7 +215,7 @@ int skr_renderer_kernel_ms(skr_renderer *r, float *mean_ms, int32_t *launches);
 /* Number of primary sphere hits the last launch (its last band) queued as level-0 nodes / parents for the
  * --gillum kernels (0 if that launch had no --gillum tree); synchronous. */
 int skr_renderer_last_parent_count(skr_renderer *r, uint32_t *n);
-/* Number of level-1 sphere hit records the last launch (its last band) queued (node and level-queue pipelines;
+/* Number of level-1 sphere hit records the last launch (its last band) queued (node pipeline;
  * 0 for the other kernel variants and at depth 2); synchronous. */
 int skr_renderer_last_level1_count(skr_renderer *r, uint32_t *n);
 /* Whole frame into HOST memory (W*H*3 bytes), synchronous; what the CLI uses. */

@@ -302,7 +302,7 @@ class Renderer:
         return int(lib().skr_tile_count(C.byref(opt.c), tile_rows, first_tile, tile_stride))
 
     def render_tiles_into(self, opt, tile_rows, first_tile, tile_stride, rgb_ptr, rgbf_ptr=None, stream=None):
-        """Enqueue the megakernel for this partition; pointers are raw device addresses."""
+        """Enqueue the kernels of this partition of the frame (skr_render_tiles); pointers are raw device addresses."""
         self._sync_switches()
         _check(lib().skr_render_tiles(self.h, C.byref(opt.c), tile_rows, first_tile, tile_stride, rgb_ptr, rgbf_ptr,
                                       stream), "skr_render_tiles")

@@ -479,7 +479,7 @@ hipError_t skr_launch_generic(const RenderParams &p_in, hipStream_t stream, cons
 		for(uint32_t row0 = 0; row0 < p.out_rows; row0 += pl.band_rows)
 		{ // every band is a complete pass
 			const uint32_t rows = p.out_rows - row0 < pl.band_rows ? p.out_rows - row0 : pl.band_rows;
-			const bool timed = hook && s == nsamp - 1 && row0 + pl.band_rows >= p.out_rows;
+			const bool timed = hook && s == nsamp - 1 && row0 == 0; // (the first band of the last sample: a full-size band)
 			p.band_row0 = row0;
 			p.band_rows = rows;
 			e = hipMemsetAsync(ctr0, 0, pl.ctr_bytes, stream);

@@ -748,7 +748,7 @@ struct NodePlan {
 	uint64_t nodes_max[SKR_NODE_LEVELS_MAX] = {};
 	uint32_t cap[SKR_NODE_LEVELS_MAX] = {};
 	size_t off_nodes[SKR_NODE_LEVELS_MAX] = {}, off_shade[SKR_NODE_LEVELS_MAX] = {}, off_recs[SKR_NODE_LEVELS_MAX] = {}, off_res[SKR_NODE_LEVELS_MAX] = {}, off_ixh[SKR_NODE_LEVELS_MAX] = {};
-	size_t off_ctr = 0, ctr_bytes = 0, off_stash = 0, total = 0, banded = 0;
+	size_t off_ctr = 0, ctr_bytes = 0, total = 0, banded = 0;
 };
 static uint32_t *lc_prefix_host(uint32_t *ctr) { return ctr + SKR_PULL_STRIDE * (2u * SKR_P1_REGIONS + 1u) + 64; } // the level's record count (region_prefix, published by skr_activate_kernel's first workgroup)
 static const uint32_t LEAF2_GRID = 256u * SKR_LEAF2_OCC;                   // every workgroup resident: 256 CUs x 4 workgroups of 4 waves
@@ -789,7 +789,6 @@ static bool plan_for(const RenderParams &p, uint32_t nblk, bool flat, NodePlan &
 	auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t) 255; return o; };
 	pl.ctr_bytes = (SKR_PULL_STRIDE + LVL_CTR_WORDS * (size_t) pl.levels) * sizeof(uint32_t); // [0] = level-0 node count, then one block per level
 	pl.off_ctr = take(pl.ctr_bytes);
-	pl.off_stash = take(256);
 	for(int L = 0; L < pl.levels; L++)
 	{
 		const size_t n = (size_t) pl.nodes_max[L];
@@ -809,7 +808,7 @@ static bool plan_for(const RenderParams &p, uint32_t nblk, bool flat, NodePlan &
 		}
 	}
 	pl.total = off;
-	pl.banded = off - (pl.off_nodes[0]); // what grows with the band; counters and the leaf kernel's stash are fixed
+	pl.banded = off - (pl.off_nodes[0]); // what grows with the band; the counters are fixed
 	return true;
 }
 
@@ -924,7 +923,6 @@ hipError_t skr_launch_nodes(const RenderParams &p_in, hipStream_t stream, const 
 	const int D = p.max_depth, last = flat ? D - 1 : D - 2; // record levels 1 .. last; the leaf kernel (flat: skr_shade_leaf_kernel) works on level `last`
 	const uint32_t blocks_x = (uint32_t) (p.width + 15) / 16, blocks = blocks_x * ((p.out_rows + 15) / 16);
 	p.blocks_x = blocks_x;
-	p.stash = reinterpret_cast<float *>(base + pl.off_stash);
 	p.qctr = ctr0; // [0]: the primary kernel counts its level-0 nodes here
 	hipError_t e = hipSuccess;
 	for(int s = 0; s < nsamp; s++)

@@ -9,14 +9,13 @@ struct f3 {
 };
 
 #define SKR_COUNTER_SHARDS 4096u
-// The GI kernel's group counter is split into SKR_PULL_QUEUES words, SKR_PULL_STRIDE uint32 apart (one word
-// sustains only ~88 atomics/us, and a 1/8 frame already needs 22 000 pulls): queue k hands out the group indices
-// congruent to k mod SKR_PULL_QUEUES.
+// Counters that thousands of waves hit with atomics sit SKR_PULL_STRIDE uint32 apart (one word sustains only ~88 atomics/us);
+// SKR_PULL_QUEUES words of that kind are reserved behind the work counters (api.cpp).
 #ifndef SKR_PULL_QUEUES
 #define SKR_PULL_QUEUES 16u
 #endif
 #define SKR_PULL_STRIDE 256u
-// level-queue pipeline: level-1 hits are appended to SKR_P1_REGIONS regions (one counter each, behind the pull counters)
+// the level pipelines append the hit records of a level to SKR_P1_REGIONS regions, one counter each
 #define SKR_P1_REGIONS 64u
 
 // The SKR_* development switches (A/B runs, tests), read from the environment ONCE per renderer (skr_renderer_create,
@@ -35,7 +34,7 @@ struct RenderParams {
 	int32_t width, height;
 	uint32_t tile_rows, first_tile, tile_stride, out_rows;
 	const uint32_t *tile_table; // device, or null: slot k of the compact output holds tile tile_table[k] (0xFFFFFFFF: an empty padding slot) instead of first_tile + k * tile_stride
-	uint32_t band_row0, band_rows; // skr_primary_kernel covers output rows [band_row0, band_row0 + band_rows) (the whole launch unless the level-queue pipeline works in bands)
+	uint32_t band_row0, band_rows; // the band of output rows [band_row0, band_row0 + band_rows) a launch of the general level pipeline works on (the whole launch elsewhere)
 	// per-frame invariants of main.cpp:134-137, computed once on the host
 	float inv_width, inv_height, aspect, angle;
 	// camera.h:8-32 (direction/up/right keep the file's magnitudes) and scene.h:24
@@ -76,11 +75,9 @@ struct RenderParams {
 	void *node_scratch;       // (host) the pipeline's one allocation
 	const float *res_in;      // (colour r1)/pdf of every child record (finalize)
 	float *res_out;           // the same for this level's records (leaf kernel; finalize of a level >= 1)
-	float *stash;             // per-wave scratch of the leaf kernel (64 lanes x 8 floats per resident wave)
-	uint32_t trace_chunks_max; // (host) bound on the trace kernel's 64-pair chunks: sizes rc_cap
-	// --shade-triangles (lane-per-pixel kernel only): triangles are surfaces, not black holes
+	// --shade-triangles (general level pipeline): triangles are surfaces, not black holes
 	int32_t shade_triangles;
-	int32_t legacy_reflect;   // --legacy-reflect (lane-per-pixel kernel only): raytrace.h:45-103 runs; sph_ks[i].w = the sphere's index of refraction
+	int32_t legacy_reflect;   // --legacy-reflect (general level pipeline): raytrace.h:45-103 runs; sph_ks[i].w = the sphere's index of refraction
 	const float4 *tri_mats;   // 3 float4 per triangle, in tris[] order: [La*ka, power] [kd] [ks] (the rows sph_amb / sph_kd / sph_ks hold for a sphere)
 	// general level pipeline (render_generic.hip): one lane per ray, every mode, any depth
 	uint32_t g_level;         // the level a launch works on (trace / activate: the rays' level, 1 = primary; finalize: the nodes' level, 0 = the camera)

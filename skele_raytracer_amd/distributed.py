@@ -3,7 +3,7 @@
 The framebuffer is cut into tiles of `tile_rows` rows; tile t belongs to rank t % world
 (interleaved, because cost is very non-uniform vertically: sky rows trace 1 ray per pixel,
 ground rows up to 1 + N + N^2).  Every rank renders its tiles into a compact, equally sized
-(padded) u8 buffer with ONE launch of the megakernel (include/skr.h skr_render_tiles:
+(padded) u8 buffer with one call of skr_render_tiles (include/skr.h:
 first_tile = rank, tile_stride = world); one collective — an all-gather of those buffers
 over RCCL/xGMI (`torch.distributed`, backend "nccl"; "gloo" in the CPU tests) — brings them
 together and the root de-interleaves.  There is no exchange inside the frame: random numbers
