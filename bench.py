@@ -167,7 +167,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None)   # default per configuration: >= 1 s of frames at one GPU for the headline (the clock the chip settles at, not its first milliseconds)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--async-frames", action="store_true", help="the pipelined frame step at N = 1 too (it is the default for N > 1)")
+    ap.add_argument("--async-frames", action="store_true", help="(the default since round 3: the pipelined frame step; kept so that old command lines run)")
     ap.add_argument("--sync-frames", action="store_true", help="libskr's frame step with the collective on the render stream (skr_comm_render_frame) instead of pipelined behind the next frame")
     ap.add_argument("--torch-gather", action="store_true", help="the round-1 frame step (torch.distributed all_gather + torch de-interleave) instead of libskr's")
     args = ap.parse_args()
@@ -259,10 +259,15 @@ def main():
     else:
         tile_map_name = "tile t -> rank t mod G"
 
-    # (at N = 1 there is no collective to hide and the two extra stream waits cost 1 %: measured 1.796 against 1.779 ms)
-    pipelined = comm is not None and (world > 1 or args.async_frames) and not args.sync_frames
+    # The pipelined step is the timed one at every N: frame f's collective and de-interleave on the communicator's stream, and the frames of the run
+    # alternating between two renderers on two streams (two frames in flight: the next frame's short kernels fill this frame's tail).  Throughput of a run
+    # of frames, which is what `value` is; the serial step (one frame at a time: its latency) is printed beside it from a side pass (--sync-frames swaps them).
+    pipelined = comm is not None and not args.sync_frames
+
+    frames_enqueued = [0]  # every frame this process asks the device for, timed or not (tools/pmc_traffic.py divides a profiled run's counters by it)
 
     def step():
+        frames_enqueued[0] += 1
         if pipelined:  # frame f's all-gather + de-interleave on the communicator's stream while this stream renders frame f + 1
             comm.render_frame_async(opt, TILE_ROWS, stream.cuda_stream, want_previous=False)
         elif comm is not None:
@@ -274,6 +279,7 @@ def main():
         # one pipelined frame before anything is timed: it either works on every rank or the run is not the one that was asked for
         ok_async, err = 1, None
         try:
+            frames_enqueued[0] += 1
             comm.render_frame_async(opt, TILE_ROWS, stream.cuda_stream, want_previous=False)
             comm.flush(stream.cuda_stream)
             torch.cuda.synchronize(dev)
@@ -309,13 +315,14 @@ def main():
     # (collective on the render stream) when the pipelined one was timed and the other way round — so that a run on G GPUs shows what
     # the pipelining buys.  Same barrier + synchronize bracket, MAX over ranks below.
     other_ms, other_name = None, None
-    if comm is not None and (world > 1 or args.async_frames or args.sync_frames):
+    if comm is not None:
         n_other = min(args.steps, 100)
         if pipelined:
             other_name = "skr_comm_render_frame (serial: collective on the render stream)"
             sync()
             t1 = time.perf_counter()
             for _ in range(n_other):
+                frames_enqueued[0] += 1
                 comm.render_frame(opt, TILE_ROWS, stream.cuda_stream)
             if world > 1:
                 dist.barrier()
@@ -324,6 +331,7 @@ def main():
         else:
             other_name = "skr_comm_render_frame_async (pipelined: collective of frame f behind the render of frame f + 1)"
             try:
+                frames_enqueued[0] += 1
                 comm.render_frame_async(opt, TILE_ROWS, stream.cuda_stream, want_previous=False)
                 comm.flush(stream.cuda_stream)
                 if world > 1:
@@ -331,6 +339,7 @@ def main():
                 torch.cuda.synchronize(dev)
                 t1 = time.perf_counter()
                 for _ in range(n_other):
+                    frames_enqueued[0] += 1
                     comm.render_frame_async(opt, TILE_ROWS, stream.cuda_stream, want_previous=False)
                 comm.flush(stream.cuda_stream)
                 if world > 1:
@@ -351,11 +360,13 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n_probe = min(args.steps, 50)
     probe = torch.zeros((k_max * TILE_ROWS, W, 3), dtype=torch.uint8, device=dev)
+    frames_enqueued[0] += 1
     r.render_tiles_into(opt, TILE_ROWS, rank, world, probe.data_ptr(), None, stream.cuda_stream)
     torch.cuda.synchronize(dev)
     r.kernel_ms()
     e0.record(stream)
     for _ in range(n_probe):
+        frames_enqueued[0] += 1
         r.render_tiles_into(opt, TILE_ROWS, rank, world, probe.data_ptr(), None, stream.cuda_stream)
     e1.record(stream)
     torch.cuda.synchronize(dev)
@@ -370,6 +381,7 @@ def main():
     if scene.info.n_triangles > 0:
         r.count_triangle_work(True)
         r.triangle_work(reset=True)
+        frames_enqueued[0] += 1
         r.render_tiles_into(opt, TILE_ROWS, rank, world, probe.data_ptr(), None, stream.cuda_stream)
         torch.cuda.synchronize(dev)
         tri = r.triangle_work(reset=True)
@@ -439,13 +451,13 @@ def main():
                        "triangle_tests_of_the_reference_loop_per_frame": tri_tests_ref / n,
                        "partition": "%d-row tiles over %d rank(s)" % (TILE_ROWS, world),
                        "frame_step": ("REHEARSAL on one GPU over gloo - not a measurement" if rehearsal else
-                                      (("libskr skr_comm_render_frame_async: tiles -> ncclAllGather (RCCL, in the library) -> de-interleave kernel on rank 0, the collective of frame f on its own stream behind the render of frame f + 1; the last frame's collective inside the timed region" if pipelined else "libskr skr_comm_render_frame: tiles -> ncclAllGather (RCCL, in the library) -> de-interleave kernel on rank 0") if comm is not None else
+                                      (("libskr skr_comm_render_frame_async: tiles -> ncclAllGather (RCCL, in the library) -> de-interleave kernel on rank 0, the collective of frame f on its own stream behind the render of frame f + 1, two frames in flight (the frames of the run alternate between the renderer and a clone of it on a second stream); the last frame's collective inside the timed region" if pipelined else "libskr skr_comm_render_frame: tiles -> ncclAllGather (RCCL, in the library) -> de-interleave kernel on rank 0") if comm is not None else
                                        "torch.distributed all_gather_into_tensor of the u8 tile buffers, rank 0 de-interleaves (torch) [--torch-gather]")) if world > 1
-                                     else (("libskr skr_comm_render_frame_async (1 GPU: tiles, then the de-interleave kernel on the communicator's stream; no collective)" if pipelined else "libskr skr_comm_render_frame (1 GPU: tiles + de-interleave kernel, no collective)") if comm is not None else "skr_render_tiles + torch de-interleave [--torch-gather]"),
+                                     else (("libskr skr_comm_render_frame_async (1 GPU: tiles, then the de-interleave kernel on the communicator's stream; no collective; two frames in flight: the frames of the run alternate between the renderer and a clone of it on a second stream — throughput of the run, the serial step's per-frame latency is config.frame_steps_ms.other)" if pipelined else "libskr skr_comm_render_frame (1 GPU: tiles + de-interleave kernel, no collective)") if comm is not None else "skr_render_tiles + torch de-interleave [--torch-gather]"),
                        "frame_steps_ms": ({"timed": ms_per_step, "timed_step": "pipelined" if pipelined else "serial", "other": other_ms, "other_step": other_name,
                                            "render_only": pipeline_ms, "note": "`other` and `render_only` come from short passes outside the timed region (MAX over ranks)"}
                                           if other_ms is not None else None),
-                       "tile_map": tile_map_name,
+                       "tile_map": tile_map_name, "frames_enqueued": frames_enqueued[0],
                        "kernel": variant, "seed": KW["seed"]},
             "roofline": {"bound": "fp32_valu", "achieved": kernel_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kernel_tflops / VALU_PEAK_TFLOPS,
                          "traffic": traffic,

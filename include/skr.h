@@ -146,6 +146,9 @@ uint64_t skr_radiance_ray_count(const skr_options *opt);
 int skr_device_count(void);
 /* Uploads the SoA scene to HBM of `device`. */
 int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out);
+/* A second renderer for the same scene on the same device with its own scratch tables: what a second frame in flight needs (the
+ * pipelined frame steps make one themselves).  It shares the uploaded scene and the work counters with `src`, which must outlive it. */
+int skr_renderer_clone(const skr_renderer *src, skr_renderer **out);
 void skr_renderer_destroy(skr_renderer *r);
 
 /* The hot path: replaces the loop nest main.cpp:125-197 (== :36-85) and every

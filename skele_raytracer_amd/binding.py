@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 EXPORTED_SYMBOLS = [
     "skr_scene_create_from_scn", "skr_scene_create_from_scn_ex", "skr_scene_create_from_arrays", "skr_scene_set_triangle_materials", "skr_scene_set_sphere_ior", "skr_scene_destroy", "skr_scene_get_info",
     "skr_scene_get_arrays", "skr_scene_get_culling", "skr_options_default", "skr_radiance_ray_count", "skr_device_count",
-    "skr_renderer_create", "skr_renderer_destroy", "skr_render_tiles", "skr_render_tile_list", "skr_tile_costs", "skr_tile_count", "skr_render_rows",
+    "skr_renderer_create", "skr_renderer_clone", "skr_renderer_destroy", "skr_render_tiles", "skr_render_tile_list", "skr_tile_costs", "skr_tile_count", "skr_render_rows",
     "skr_renderer_read_counters", "skr_renderer_read_work", "skr_renderer_read_triangle_work", "skr_renderer_count_triangle_work", "skr_renderer_kernel_work", "skr_renderer_reload_switches", "skr_renderer_kernel_timing", "skr_renderer_kernel_ms", "skr_renderer_last_parent_count", "skr_renderer_last_level1_count", "skr_render_frame_host", "skr_render_progressive_host", "skr_accumulate", "skr_resolve_accumulated", "skr_write_png", "skr_write_pfm", "skr_write_ppm", "skr_last_error",
     "skr_kernel_variant", "skr_debug_eval",
     "skr_rccl_available", "skr_multi_create", "skr_multi_destroy", "skr_multi_device_count", "skr_multi_renderer", "skr_multi_render_frame",

@@ -43,6 +43,8 @@ struct skr_renderer {
 	int device = 0;
 	skr_scene_info info{};
 	float4 *d_blob = nullptr; // one allocation: geom | amb | kd | ks | lights | tris | chunk trees | triangle materials
+	size_t blob_bytes = 0;
+	bool is_clone = false;    // skr_renderer_clone: the scene blob and the work counters belong to the renderer it was cloned from
 	size_t off_amb = 0, off_kd = 0, off_ks = 0, off_lights = 0, off_tris = 0, off_chunks = 0, off_tri_mats = 0;
 	int n_chunks = 0, chunk_size = 0, cones = 0;
 	size_t chunk_stride = 0;
@@ -81,6 +83,9 @@ static void load_switches(SkrSwitches &sw)
 	if(const char *e = getenv("SKR_LEVELS_BUDGET_MB")) sw.budget_mb = atoi(e) > 0 ? atoi(e) : 1;
 	if(const char *e = getenv("SKR_FLAT")) sw.flat = atoi(e) > 0 ? 1 : -1;
 }
+
+// (multi_gpu.cpp) a clone follows its source's development switches: tests change them between frames
+void skr_copy_switches(skr_renderer *dst, const skr_renderer *src) { dst->sw = src->sw; }
 
 extern "C" {
 
@@ -154,6 +159,7 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	if(nt3) memcpy(&blob[r->off_tris], scene->tris.data(), nt3 * 16);
 	if(nch) memcpy(&blob[r->off_chunks], scene->tri_chunks.data(), nch * 16);
 	if(ntm) memcpy(&blob[r->off_tri_mats], scene->tri_mats.data(), ntm * 16);
+	r->blob_bytes = blob.size() * 16;
 	hipError_t e = hipMalloc((void **) &r->d_blob, blob.size() * 16);
 	if(e == hipSuccess) e = hipMemcpy(r->d_blob, blob.data(), blob.size() * 16, hipMemcpyHostToDevice);
 	if(e == hipSuccess) e = hipMalloc((void **) &r->d_counters, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long) + (SKR_PULL_QUEUES + 2 + 2 * SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t));
@@ -173,13 +179,44 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	return SKR_OK;
 }
 
+// A second renderer for the same scene on the same device with its own scratch (tables, accumulation buffers, timing events) — what a
+// second frame in flight needs (multi_gpu.cpp: consecutive frames of a run alternate between a renderer and its clone on two streams).
+// The scene blob (read-only) and the work counters (atomics) are SHARED with `src`, which must outlive the clone: rays counted by
+// either are read through either.
+int skr_renderer_clone(const skr_renderer *src, skr_renderer **out)
+{
+	if(!src || !out)
+	{
+		skr_set_error("skr_renderer_clone: null argument");
+		return SKR_ERR_ARG;
+	}
+	*out = nullptr;
+	SKR_HIP(hipSetDevice(src->device));
+	skr_renderer *r = new skr_renderer();
+	r->device = src->device;
+	r->info = src->info;
+	r->d_blob = src->d_blob;
+	r->blob_bytes = src->blob_bytes;
+	r->is_clone = true;
+	r->off_amb = src->off_amb; r->off_kd = src->off_kd; r->off_ks = src->off_ks; r->off_lights = src->off_lights;
+	r->off_tris = src->off_tris; r->off_chunks = src->off_chunks; r->off_tri_mats = src->off_tri_mats;
+	r->n_chunks = src->n_chunks; r->chunk_size = src->chunk_size; r->cones = src->cones; r->chunk_stride = src->chunk_stride;
+	r->d_counters = src->d_counters;
+	r->d_tri_work = src->d_tri_work;
+	r->lds_limit = src->lds_limit;
+	r->pow_steps = src->pow_steps;
+	r->sw = src->sw;
+	*out = r;
+	return SKR_OK;
+}
+
 void skr_renderer_destroy(skr_renderer *r)
 {
 	if(!r) return;
 	(void) hipSetDevice(r->device);
-	if(r->d_blob) (void) hipFree(r->d_blob);
-	if(r->d_counters) (void) hipFree(r->d_counters);
-	if(r->d_tri_work) (void) hipFree(r->d_tri_work);
+	if(r->d_blob && !r->is_clone) (void) hipFree(r->d_blob);
+	if(r->d_counters && !r->is_clone) (void) hipFree(r->d_counters);
+	if(r->d_tri_work && !r->is_clone) (void) hipFree(r->d_tri_work);
 	if(r->d_snap) (void) hipFree(r->d_snap);
 	if(r->d_nodes) (void) hipFree(r->d_nodes);
 	if(r->d_acc) (void) hipFree(r->d_acc);

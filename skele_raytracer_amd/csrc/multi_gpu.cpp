@@ -337,7 +337,23 @@ struct skr_comm {
 	hipEvent_t rendered[2] = {nullptr, nullptr}, gathered[2] = {nullptr, nullptr};
 	bool in_flight[2] = {false, false};
 	uint64_t async_frames = 0;
+	// two frames in flight: odd frames of a run are rendered by a clone of the renderer (its own tables) on a stream of the communicator's
+	skr_renderer *r2 = nullptr;
+	hipStream_t rs2 = nullptr;
+	hipEvent_t called = nullptr;
 };
+
+void skr_copy_switches(skr_renderer *dst, const skr_renderer *src); // api.cpp
+
+// A rank's share of a frame is eight short dependent kernels: two frames in flight on two streams fill each other's ramps and
+// tails — 1/8 of the headline frame 0.258 -> 0.217 ms per frame, 1/4 0.454 -> 0.427, 1/2 0.836 -> 0.800 (tools/inflight.py); a whole frame
+// through this step, with the de-interleave behind it, 1.570 -> 1.513 ms.  So a run of frames alternates between the renderer and a clone of
+// it (a second set of tables: 1.7 GB for the headline frame); SKR_INFLIGHT=1 keeps it to one.
+static bool two_in_flight()
+{
+	if(const char *e = getenv("SKR_INFLIGHT")) return atoi(e) >= 2;
+	return true;
+}
 
 extern "C" {
 
@@ -408,6 +424,10 @@ void skr_comm_destroy(skr_comm *c)
 		if(c->gathered[k]) (void) hipEventDestroy(c->gathered[k]);
 	}
 	if(c->cs) (void) hipStreamDestroy(c->cs);
+	if(c->rs2) (void) hipStreamSynchronize(c->rs2);
+	if(c->r2) skr_renderer_destroy(c->r2);
+	if(c->rs2) (void) hipStreamDestroy(c->rs2);
+	if(c->called) (void) hipEventDestroy(c->called);
 	if(c->comm) (void) rccl().CommDestroy(c->comm);
 	delete c;
 }
@@ -435,8 +455,9 @@ int skr_comm_render_frame(skr_comm *c, const skr_options *opt, uint32_t tile_row
 }
 
 // The same frame step with the collective off the render stream: frame f's all-gather and de-interleave run on a stream of the
-// communicator's own while `stream` goes on to render frame f + 1 into the other of two buffer sets — on 8 GPUs the collective
-// is a third of a 0.3 ms share, and nothing in the next frame depends on it.  *d_prev_frame (rank 0): the frame of the
+// communicator's own while frame f + 1 is rendered into the other of two buffer sets — on 8 GPUs the collective
+// is a third of a 0.3 ms share, and nothing in the next frame depends on it.  The frames of a run also
+// alternate between two renderers on two streams (two_in_flight above): throughput of a run, not the latency of a frame.  *d_prev_frame (rank 0): the frame of the
 // PREVIOUS call, complete in `stream` order after this call (NULL on the first call and on the other ranks).
 int skr_comm_render_frame_async(skr_comm *c, const skr_options *opt, uint32_t tile_rows, uint8_t **d_prev_frame, void *stream)
 {
@@ -454,7 +475,23 @@ int skr_comm_render_frame_async(skr_comm *c, const skr_options *opt, uint32_t ti
 		}
 	}
 	const int s = (int) (c->async_frames & 1u), prev = s ^ 1;
-	hipStream_t rs = (hipStream_t) stream;
+	hipStream_t rs = (hipStream_t) stream; // the stream this frame is rendered on
+	skr_renderer *rr = c->r;
+	if(s == 1 && two_in_flight())
+	{ // odd frames: the clone, on the communicator's second render stream, behind whatever the caller's stream holds at this call
+		if(!c->r2)
+		{
+			rc = skr_renderer_clone(c->r, &c->r2);
+			if(rc != SKR_OK) return rc;
+			SKR_HIP(hipStreamCreateWithFlags(&c->rs2, hipStreamNonBlocking));
+			SKR_HIP(hipEventCreateWithFlags(&c->called, hipEventDisableTiming));
+		}
+		skr_copy_switches(c->r2, c->r);
+		SKR_HIP(hipEventRecord(c->called, (hipStream_t) stream));
+		SKR_HIP(hipStreamWaitEvent(c->rs2, c->called, 0));
+		rs = c->rs2;
+		rr = c->r2;
+	}
 	RankBuffers &b = c->abuf[s];
 	if(c->in_flight[s])
 	{ // the collective of frame f - 2 read these buffers (a change of geometry frees them: wait on the host then)
@@ -470,7 +507,7 @@ int skr_comm_render_frame_async(skr_comm *c, const skr_options *opt, uint32_t ti
 	rc = ensure_map(c->map, c->r, opt, tile_rows, (uint32_t) c->world, (uint32_t) c->rank, nullptr);
 	if(rc != SKR_OK) return rc;
 	uint8_t *mine = b.d_gather + (size_t) c->rank * b.chunk;
-	rc = skr_render_tile_list(c->r, opt, tile_rows, c->map.d_tiles, c->map.k_max, mine, nullptr, stream);
+	rc = skr_render_tile_list(rr, opt, tile_rows, c->map.d_tiles, c->map.k_max, mine, nullptr, rs);
 	if(rc != SKR_OK) return rc;
 	SKR_HIP(hipEventRecord(c->rendered[s], rs));
 	SKR_HIP(hipStreamWaitEvent(c->cs, c->rendered[s], 0));
@@ -484,7 +521,7 @@ int skr_comm_render_frame_async(skr_comm *c, const skr_options *opt, uint32_t ti
 		*d_prev_frame = nullptr;
 		if(c->in_flight[prev])
 		{
-			SKR_HIP(hipStreamWaitEvent(rs, c->gathered[prev], 0));
+			SKR_HIP(hipStreamWaitEvent((hipStream_t) stream, c->gathered[prev], 0));
 			if(c->rank == 0) *d_prev_frame = c->abuf[prev].d_frame;
 		}
 	}

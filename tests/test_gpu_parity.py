@@ -678,10 +678,14 @@ def test_multi_rank_paths_rehearsed_on_one_gpu(gpu, tmp_path, world):
     assert "cpu_baseline" not in out and out["roofline"]["kernel_ms"] > 0
 
 
-def test_pipelined_frame_step_returns_every_frame(gpu):
+@pytest.mark.parametrize("inflight", ["1", "2"])
+def test_pipelined_frame_step_returns_every_frame(gpu, monkeypatch, inflight):
     """skr_comm_render_frame_async: the collective and the de-interleave of frame f on the communicator's own stream while the
     caller's stream renders frame f + 1.  Six frames with six seeds (and a change of geometry in between): every frame handed back —
-    one call late, the last one by skr_comm_flush — must be the frame a plain render of that seed gives."""
+    one call late, the last one by skr_comm_flush — must be the frame a plain render of that seed gives.  SKR_INFLIGHT=2: what a
+    world of more than one rank does by default — the odd frames of the run on a clone of the renderer (skr_renderer_clone) and a
+    second stream, two shares in flight; the work counters of both land in the one set."""
+    monkeypatch.setenv("SKR_INFLIGHT", inflight)
     r = renderer("spheres2.scn")
     st = gpu.cuda.current_stream()
 
@@ -698,6 +702,8 @@ def test_pipelined_frame_step_returns_every_frame(gpu):
         c = binding.Comm(r, 0, 1, binding.comm_unique_id() if with_rccl else None)
         shapes = [(333, 187, 8)] * 3 + [(200, 113, 16)] * 3
         got, want = [], []
+        gpu.cuda.synchronize()
+        r.counters(reset=True)
         for k, (w, h, tile_rows) in enumerate(shapes):
             opt = skr.Options(w, h, gillum=4, shadow=True, seed=100 + k)
             prev = c.render_frame_async(opt, tile_rows, st.cuda_stream)
@@ -708,10 +714,13 @@ def test_pipelined_frame_step_returns_every_frame(gpu):
                 got.append(frame_at(prev, pw, ph))
         last = c.flush(st.cuda_stream)
         got.append(frame_at(last, shapes[-1][0], shapes[-1][1]))
+        in_run = r.counters(reset=True)
         c.close()
         for k, (w, h, _) in enumerate(shapes):
             f, _ = r.render(skr.Options(w, h, gillum=4, shadow=True, seed=100 + k))
             want.append(f.cpu().numpy())
+        gpu.cuda.synchronize()
+        assert in_run == r.counters(reset=True)  # (every ray of the run counted once, whichever renderer traced it)
         assert len(got) == len(want) == 6
         for k in range(6):
             assert np.array_equal(got[k], want[k]), (with_rccl, k)

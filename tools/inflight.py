@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT)
 import torch, skele_raytracer_amd as skr
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # one rank's share of the frame cut over G GPUs (tile t -> rank t mod G) instead of the whole frame
 W, H = 1920, 1080
 sc = skr.parse_scene(os.path.join(ROOT, "tests/golden/scenes/spheres2.scn"))
 opt = skr.Options(W, H, gillum=16, shadow=True, seed=20261004)
@@ -15,10 +16,12 @@ dev = torch.device("cuda", 0)
 for n in (1, 2, 3):
     rs = [skr.Renderer(sc) for _ in range(n)]
     streams = [torch.cuda.Stream(dev) for _ in range(n)]
-    bufs = [torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(n)]
+    rows = rs[0].tile_count(opt, 8, 0, G) * 8 if G > 1 else H
+    bufs = [torch.zeros((rows, W, 3), dtype=torch.uint8, device=dev) for _ in range(n)]
     def frame(i):
         k = i % n
-        rs[k].render_tiles_into(opt, H, 0, 1, bufs[k].data_ptr(), None, streams[k].cuda_stream)
+        if G > 1: rs[k].render_tiles_into(opt, 8, 0, G, bufs[k].data_ptr(), None, streams[k].cuda_stream)
+        else: rs[k].render_tiles_into(opt, H, 0, 1, bufs[k].data_ptr(), None, streams[k].cuda_stream)
     for i in range(3 * n):
         frame(i)
     torch.cuda.synchronize()
@@ -30,4 +33,4 @@ for n in (1, 2, 3):
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) / K * 1e3)
     same = all(torch.equal(bufs[0], b) for b in bufs[1:])
-    print("frames in flight %d: %.4f ms per frame (frames equal: %s)" % (n, best, same), flush=True)
+    print("G=%d frames in flight %d: %.4f ms per frame (frames equal: %s) [%s]" % (G, n, best, same, rs[0].kernel_variant()), flush=True)

@@ -2,7 +2,8 @@
 """HBM traffic of one frame over ALL its kernels from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
 `bench.py [--config C] --steps 2 --warmup 1 --no-cpu-baseline`, written with the git blob hashes of the kernel sources it was
 measured on (bench.py reports it only while those hashes match).  Every dispatch of every skr_ kernel is summed and divided by the
-frames that command renders (1 warm-up + 2 timed + 3 of the kernel-timing pass = 6), so configurations whose frame takes several
+frames that command asked the device for — bench.py counts them (config.frames_enqueued in its JSON line, found in the passes' logs: warm-up,
+timed frames, the other frame step's side pass, the kernel-timing pass, a mesh's counting frame) —, so configurations whose frame takes several
 launches of a kernel (AA samples, bands) are counted whole.
 Usage: pmc_traffic.py DIR_WITH_THE_TWO_PASSES OUT.json [CONFIG [VARIANT]]"""
 import csv, glob, json, os, sys
@@ -14,7 +15,18 @@ import bench
 root, out = sys.argv[1], sys.argv[2]
 config = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 variant = sys.argv[4] if len(sys.argv) > 4 else ("node_levels_v5" if config in (3, 5) else "direct_v3")
-FRAMES = 6
+FRAMES = None
+for log in sorted(glob.glob(os.path.join(root, "*.log"))):
+    for line in open(log, errors="replace"):
+        if line.startswith("{") and '"frames_enqueued"' in line:
+            try:
+                n = int(json.loads(line)["config"]["frames_enqueued"])
+            except Exception:
+                continue
+            assert FRAMES in (None, n), "the passes rendered different numbers of frames: %s and %s" % (FRAMES, n)
+            FRAMES = n
+if FRAMES is None:
+    sys.exit("no bench.py JSON line with config.frames_enqueued in %s/*.log" % root)
 acc = defaultdict(lambda: defaultdict(float))   # kernel -> counter -> sum over dispatches
 launches = defaultdict(set)
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
