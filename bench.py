@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--async-frames", action="store_true", help="(the default since round 3: the pipelined frame step; kept so that old command lines run)")
     ap.add_argument("--sync-frames", action="store_true", help="libskr's frame step with the collective on the render stream (skr_comm_render_frame) instead of pipelined behind the next frame")
+    ap.add_argument("--no-side-pass", action="store_true", help="do not time the other frame step beside the timed one (profiling runs: a trace of --sync-frames --no-side-pass holds serial frames only)")
     ap.add_argument("--torch-gather", action="store_true", help="the round-1 frame step (torch.distributed all_gather + torch de-interleave) instead of libskr's")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -315,7 +316,7 @@ def main():
     # (collective on the render stream) when the pipelined one was timed and the other way round — so that a run on G GPUs shows what
     # the pipelining buys.  Same barrier + synchronize bracket, MAX over ranks below.
     other_ms, other_name = None, None
-    if comm is not None:
+    if comm is not None and not args.no_side_pass:
         n_other = min(args.steps, 100)
         if pipelined:
             other_name = "skr_comm_render_frame (serial: collective on the render stream)"

@@ -9,8 +9,12 @@ export BENCH_ARGS="--config $CFG"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 STEPS=$([ "$CFG" = 5 ] && echo "--steps 2 --warmup 1" || echo "--steps 20 --warmup 3")
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $BENCH_ARGS $STEPS --no-cpu-baseline > $OUT/trace.log 2>&1
+# two kernel traces: the serial frame step (--sync-frames: one frame at a time, every kernel alone on the device — the durations bench.py's
+# roofline.kernel_ms must agree with) and the default, pipelined one (two frames in flight: kernels of consecutive frames overlap and stretch each other)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $BENCH_ARGS $STEPS --no-cpu-baseline --sync-frames --no-side-pass > $OUT/trace.log 2>&1
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -- python3 $R/bench.py $BENCH_ARGS $STEPS --no-cpu-baseline --no-side-pass > $OUT/trace_pipelined.log 2>&1
+cp $(find $OUT/trace_pipelined -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_pipelined.csv
 cd $R
 if [ "$CFG" = 5 ]; then
   bash tools/pmc_pass.sh gpurun_out/$1/pmc FETCH_SIZE WRITE_SIZE
