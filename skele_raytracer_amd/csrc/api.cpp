@@ -514,6 +514,7 @@ int skr_tile_costs(skr_renderer *r, const skr_options *opt, uint32_t tile_rows, 
 	if(rc != SKR_OK) return rc;
 	SKR_HIP(hipSetDevice(r->device));
 	const uint32_t T = ((uint32_t) opt->height + tile_rows - 1) / tile_rows;
+	SKR_HIP(hipDeviceSynchronize()); // (frames still in flight on other streams add to the counters this probe borrows)
 	std::vector<unsigned long long> saved((size_t) SKR_COUNTER_SHARDS * 4 + 8);
 	SKR_HIP(hipMemcpy(saved.data(), r->d_counters, saved.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	SKR_HIP(hipMemset(r->d_counters, 0, saved.size() * sizeof(unsigned long long)));

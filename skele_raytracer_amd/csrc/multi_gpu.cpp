@@ -576,6 +576,8 @@ struct skr_multi {
 	bool in_flight[2] = {false, false};
 	uint64_t async_frames = 0;
 	int async_set = -1; // >= 0: the workers render into abufs[async_set] (and order themselves behind its last collective)
+	std::vector<skr_renderer *> renderers2; // two frames in flight (two_in_flight above): the odd frames of a run on a clone per device ...
+	std::vector<hipStream_t> streams2;      // ... and a second stream
 	hipEvent_t e0 = nullptr, e1 = nullptr; // root stream: frame time
 	// one worker thread per device (a single thread would enqueue 8 devices' launch sequences one after the other)
 	std::vector<std::thread> workers;
@@ -598,8 +600,23 @@ int multi_render_rank(skr_multi *m, int i)
 	SKR_HIP(hipSetDevice(m->devices[i]));
 	const int set = m->async_set;
 	RankBuffers &b = set >= 0 ? m->abufs[set][i] : m->bufs[i];
-	if(set >= 0 && m->in_flight[set]) SKR_HIP(hipStreamWaitEvent(m->streams[i], m->gathered[set][i], 0)); // the collective of frame f - 2 read these buffers
-	int rc = size_buffers(b, m->opt, m->tile_rows, (uint32_t) m->n, i == 0);
+	int rc = SKR_OK;
+	skr_renderer *rr = m->renderers[i];
+	hipStream_t rs = m->streams[i];
+	if(set == 1 && two_in_flight())
+	{ // buffer set 1 always belongs to the clone and its stream (made by this device's own thread, once)
+		if(!m->renderers2[i])
+		{
+			rc = skr_renderer_clone(m->renderers[i], &m->renderers2[i]);
+			if(rc != SKR_OK) return rc;
+			SKR_HIP(hipStreamCreateWithFlags(&m->streams2[i], hipStreamNonBlocking));
+		}
+		skr_copy_switches(m->renderers2[i], m->renderers[i]);
+		rr = m->renderers2[i];
+		rs = m->streams2[i];
+	}
+	if(set >= 0 && m->in_flight[set]) SKR_HIP(hipStreamWaitEvent(rs, m->gathered[set][i], 0)); // the collective of frame f - 2 read these buffers
+	rc = size_buffers(b, m->opt, m->tile_rows, (uint32_t) m->n, i == 0);
 	if(rc != SKR_OK) return rc;
 	if(i != 0)
 	{ // (device 0's map was made by the caller before the workers were woken: here it is only uploaded)
@@ -607,9 +624,9 @@ int multi_render_rank(skr_multi *m, int i)
 		if(rc != SKR_OK) return rc;
 	}
 	if(i == 0 && set < 0) SKR_HIP(hipEventRecord(m->e0, m->streams[0]));
-	rc = skr_render_tile_list(m->renderers[i], m->opt, m->tile_rows, m->maps[i].d_tiles, m->maps[i].k_max, b.d_gather + (size_t) i * b.chunk, nullptr, m->streams[i]);
+	rc = skr_render_tile_list(rr, m->opt, m->tile_rows, m->maps[i].d_tiles, m->maps[i].k_max, b.d_gather + (size_t) i * b.chunk, nullptr, rs);
 	if(rc != SKR_OK) return rc;
-	if(set >= 0) SKR_HIP(hipEventRecord(m->rendered[set][i], m->streams[i]));
+	if(set >= 0) SKR_HIP(hipEventRecord(m->rendered[set][i], rs));
 	return SKR_OK;
 }
 
@@ -716,6 +733,8 @@ int skr_multi_create(const skr_scene *scene, int n_devices, const int *devices, 
 	for(int i = 0; i < n_devices; i++) m->devices[i] = devices ? devices[i] : i;
 	m->renderers.assign(n_devices, nullptr);
 	m->streams.assign(n_devices, nullptr);
+	m->renderers2.assign(n_devices, nullptr);
+	m->streams2.assign(n_devices, nullptr);
 	m->comms.assign(n_devices, nullptr);
 	m->bufs.resize(n_devices);
 	m->maps.resize(n_devices);
@@ -780,6 +799,9 @@ void skr_multi_destroy(skr_multi *m)
 		}
 		if(i < (int) m->cstreams.size() && m->cstreams[i]) (void) hipStreamDestroy(m->cstreams[i]);
 		if(m->comms[i]) (void) rccl().CommDestroy(m->comms[i]);
+		if(i < (int) m->streams2.size() && m->streams2[i]) (void) hipStreamSynchronize(m->streams2[i]);
+		if(i < (int) m->renderers2.size() && m->renderers2[i]) skr_renderer_destroy(m->renderers2[i]);
+		if(i < (int) m->streams2.size() && m->streams2[i]) (void) hipStreamDestroy(m->streams2[i]);
 		if(m->streams[i]) (void) hipStreamDestroy(m->streams[i]);
 		if(m->renderers[i]) skr_renderer_destroy(m->renderers[i]);
 	}
