@@ -81,6 +81,7 @@ def lib():
     L.skr_radiance_ray_count.restype = C.c_uint64
     L.skr_device_count.restype = C.c_int
     L.skr_renderer_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.skr_renderer_clone.argtypes = [vp, C.POINTER(vp)]
     L.skr_renderer_destroy.argtypes = [vp]
     L.skr_renderer_destroy.restype = None
     L.skr_render_tiles.argtypes = [vp, C.POINTER(COptions), C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
@@ -275,6 +276,17 @@ class Renderer:
         _check(lib().skr_renderer_create(scene.h, device, C.byref(h)), "skr_renderer_create")
         self.h = h
         self._env = self._switch_env()
+
+    def clone(self):
+        """skr_renderer_clone: a second renderer on the same uploaded scene with its own tables (a second frame in flight); it shares this
+        renderer's work counters and must be closed before it."""
+        other = Renderer.__new__(Renderer)
+        other.scene, other.device, other._source = self.scene, self.device, self
+        h = C.c_void_p()
+        _check(lib().skr_renderer_clone(self.h, C.byref(h)), "skr_renderer_clone")
+        other.h = h
+        other._env = self._env
+        return other
 
     @staticmethod
     def _switch_env():

@@ -726,6 +726,31 @@ def test_pipelined_frame_step_returns_every_frame(gpu, monkeypatch, inflight):
             assert np.array_equal(got[k], want[k]), (with_rccl, k)
 
 
+def test_a_clone_renders_the_same_frames_on_its_own_stream(gpu):
+    """skr_renderer_clone: the same uploaded scene, its own tables.  Two different frames enqueued at once on two streams — one on the
+    renderer, one on its clone — are each the frame a plain render gives, and the shared work counters hold the rays of both."""
+    r = renderer("spheres2.scn")
+    a_opt, b_opt = skr.Options(320, 180, gillum=8, shadow=True, seed=5), skr.Options(256, 144, gillum=3, depth=4, shadow=True, seed=6)
+    want_a, _ = r.render(a_opt)
+    want_b, _ = r.render(b_opt)
+    gpu.cuda.synchronize()
+    each = r.counters(reset=True)
+    c = r.clone()
+    sa, sb = gpu.cuda.Stream(), gpu.cuda.Stream()
+    buf_a = gpu.zeros((180, 320, 3), dtype=gpu.uint8, device="cuda")
+    buf_b = gpu.zeros((144, 256, 3), dtype=gpu.uint8, device="cuda")
+    for _ in range(3):
+        r.render_tiles_into(a_opt, 180, 0, 1, buf_a.data_ptr(), None, sa.cuda_stream)
+        c.render_tiles_into(b_opt, 144, 0, 1, buf_b.data_ptr(), None, sb.cuda_stream)
+    gpu.cuda.synchronize()
+    assert gpu.equal(buf_a, want_a) and gpu.equal(buf_b, want_b)
+    both = c.counters(reset=True)  # (read through either)
+    assert both["radiance_rays"] == 3 * each["radiance_rays"] and both["sphere_hits"] == 3 * each["sphere_hits"]
+    c.close()
+    again, _ = r.render(a_opt)
+    assert gpu.equal(again, want_a)  # (the source outlives its clone)
+
+
 def test_native_frame_step_on_one_gpu(gpu, tmp_path):
     """The multi-GPU frame step that lives inside libskr (include/skr.h "multi-GPU": tiles into the gather buffer, ONE
     ncclAllGather, de-interleave kernel), as far as a one-GPU box can run it: a world of one with a real RCCL communicator
