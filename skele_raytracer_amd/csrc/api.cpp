@@ -138,7 +138,7 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	const size_t ntm = scene->tri_mats.size();
 	r->off_tri_mats = 4 * ns + nl2 + nt3 + nch;
 	const size_t total = 4 * ns + nl2 + nt3 + nch + ntm;
-	std::vector<skr_f4> blob(total > 0 ? total : 1);
+	std::vector<skr_f4> blob(total + 16); // (+ 16 rows: the sphere loops ask for the rows of a trip ahead without a bounds test, shade_common.h sphere_rows)
 	if(ns)
 	{
 		memcpy(&blob[0], scene->sph_geom.data(), ns * 16);

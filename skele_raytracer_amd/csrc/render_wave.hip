@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) SKR_PRIMARY_ATTR void skr_primary_kernel(const
 		s_camec[i] = row;
 	}
 	__syncthreads();
-	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work, SKR_GEOM_SMEM ? p.sph_geom : s_geom};
+	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work, p.sph_geom};
 
 	const int wave = tid >> 6, lane = tid & 63;
 	const int lx = ((wave & 1) << 3) | (lane & 7), ly = ((wave >> 1) << 3) | (lane >> 3);

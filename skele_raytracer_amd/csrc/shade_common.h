@@ -25,30 +25,56 @@ struct SceneView {
 	int chunk;            // triangles per chunk sphere (tri_chunks.h)
 	int cones;            // some entry carries a tight radius for non-grazing rays
 	unsigned long long *tri_work; // HBM, or null (not counting): SKR_TRI_WORK_SHARDS x {culling-sphere tests, triangle tests} the walks executed (lanes that needed them)
-	const float4 *geom_u; // the rows of `geom` for the loops that walk the spheres in order with a wave-uniform index (SKR_GEOM_SMEM: in HBM,
-	                      // read by scalar loads into SGPRs; otherwise the LDS copy)
+	const float4 *geom_u; // HBM: the same rows as `geom`, for the loops that walk the spheres in order with a wave-uniform index (sphere_rows)
 };
-#ifndef SKR_GEOM_SMEM
-#define SKR_GEOM_SMEM 0
-#endif
-// row i of sv.geom_u, i wave-uniform.  SKR_GEOM_SMEM: through the constant address space, which is what makes the compiler take the
-// scalar path (s_load_dwordx4 into SGPRs) — through the plain pointer it cannot prove that no store of the kernel aliases the row and
-// issues a vector load with a uniform address.
 typedef float skr_v4f __attribute__((ext_vector_type(4)));
+// One aligned 16-byte row of a table that no kernel writes, at a wave-uniform index, through the constant address space: that is what
+// makes the compiler take the scalar path (s_load_dwordx4 into SGPRs) — through a plain pointer it cannot prove that no store of the
+// kernel aliases the row and issues a vector load with a uniform address.
 SKR_DEV float4 load_const4(const float4 *base, int i)
 {
 	const skr_v4f __attribute__((address_space(4))) *q = (const skr_v4f __attribute__((address_space(4))) *) (unsigned long long) base;
 	const skr_v4f v = q[i];
 	return make_float4(v.x, v.y, v.z, v.w);
 }
-SKR_DEV float4 geom_row_u(const SceneView &sv, int i)
-{
-#if SKR_GEOM_SMEM
-	return load_const4(sv.geom_u, i);
-#else
-	return sv.geom_u[i];
+
+// The sphere loops of the level pipelines (closest_pair_deferred, occluded_pair<false>): `test(row, index)` for every sphere in order,
+// SKR_SPHERE_TRIP spheres per trip, the rows of the next trip asked for a trip ahead with ONE scalar load (s_load_dwordx8 / x16: the rows
+// are consecutive).  The rows come through the scalar cache into SGPRs (geom_u), so the spheres in flight cost no vector register for
+// their data — and several independent tests per trip are what a SIMD with four waves wants.  Headline leaf kernel, same box, spheres
+// per trip 1 / 2 / 3 / 4 / 5 / 6 / 8: 1.240 / 1.205 / 1.207 / 1.19 / 1.240 / 1.224 / 1.282 ms (LDS rows, one per trip: 1.25; LDS rows,
+// two per trip: 1.35 — the second sphere's registers spill; scalar rows fetched one by one with a bounds test each: 1.25).  The lanes of
+// these kernels are incoherent; the direct kernel's coherent loops keep LDS rows and their wave-wide early exit.
+#ifndef SKR_SPHERE_TRIP
+#define SKR_SPHERE_TRIP 4
 #endif
+template <typename F>
+SKR_DEV void sphere_rows(const SceneView &sv, F test)
+{
+	constexpr int K = SKR_SPHERE_TRIP;
+	auto row = [&](int i) { return load_const4(sv.geom_u, i); }; // (up to 2 K - 1 rows behind the spheres are asked for and never used: the scene blob is padded for them, api.cpp)
+	float4 nx[K];
+#pragma unroll
+	for(int k = 0; k < K; k++) nx[k] = row(k);
+	int i = 0;
+	for(; i + K <= sv.ns; i += K)
+	{
+		float4 g[K];
+#pragma unroll
+		for(int k = 0; k < K; k++)
+		{
+			g[k] = nx[k];
+			nx[k] = row(i + K + k);
+		}
+		__builtin_amdgcn_sched_barrier(0); // the next trip's rows are asked for here, a whole trip ahead of their use
+#pragma unroll
+		for(int k = 0; k < K; k++) test(g[k], i + k);
+	}
+#pragma unroll
+	for(int k = 0; k < K - 1; k++)
+		if(i + k < sv.ns) test(nx[k], i + k);
 }
+
 // Row i of the mesh tables (triangles, culling data: HBM, never written by a kernel), i wave-uniform: one s_load_dwordx4 into SGPRs.
 // Through the plain pointer the compiler issues a VECTOR load with a uniform address (it cannot prove that no store of the kernel
 // aliases the table): 26 M vector-memory instructions per dragon frame, found in the round-3 counters (SQ_INSTS_VMEM against
@@ -351,15 +377,19 @@ SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second,
 			}
 		}
 	};
-	float4 g_next = geom_row_u(sv, 0);
-	for(int i = 0; i < sv.ns; i++)
+	if(COHERENT)
 	{
-		const float4 g = g_next;
-		g_next = geom_row_u(sv, i + 1);
-		__builtin_amdgcn_sched_barrier(0); // (as in closest_pair_deferred)
-		test(g, i);
-		if(COHERENT && __all(occ0 && occ1)) break;
+		float4 g_next = sv.geom[0];
+		for(int i = 0; i < sv.ns; i++)
+		{
+			const float4 g = g_next;
+			g_next = sv.geom[i + 1];
+			__builtin_amdgcn_sched_barrier(0); // the prefetch is issued here, a whole trip ahead of its use, not behind the arithmetic
+			test(g, i);
+			if(__all(occ0 && occ1)) break;
+		}
 	}
+	else sphere_rows(sv, test);
 	if(!occ0) tests += (uint32_t) sv.ns;
 	if(second && !occ1) tests += (uint32_t) sv.ns;
 	if(!second) occ1 = false;

@@ -79,13 +79,8 @@ SKR_DEV void closest_pair_deferred(const SceneView &sv, f3 o, f3 d0, f3 d1, bool
 {
 	s0 = BestState{-1, __builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f, 0.0f};
 	s1 = s0;
-	float4 g_next = geom_row_u(sv, 0);
-	// (one sphere per trip: `#pragma unroll 2` is ignored for a run-time trip count, and two per trip written out by hand cost more in registers than the copies save)
-	for(int i = 0; i < sv.ns; i++)
+	auto test = [&](const float4 g, int i)
 	{
-		const float4 g = g_next;
-		g_next = geom_row_u(sv, i + 1);
-		__builtin_amdgcn_sched_barrier(0); // the prefetch is issued here, a whole trip ahead of its use, not behind the arithmetic
 		const f3 e = o - ld3(g);
 		const float c = dot3(e, e) - g.w;
 		f2 b, D;
@@ -102,21 +97,11 @@ SKR_DEV void closest_pair_deferred(const SceneView &sv, f3 o, f3 d0, f3 d1, bool
 			float l0 = lo.x, h0 = hi.x, l1 = lo.y, h1 = hi.y;
 			const bool acc0 = cand0 && bracket_decide(rp.sane0, rp.two_a.x, b.x, D.x, l0, h0);
 			const bool acc1 = cand1 && bracket_decide(rp.sane1, rp.two_a.y, b.y, D.y, l1, h1);
-#if defined(SKR_DIAG) && SKR_DIAG
-			{ // how many candidates a t2 <= 1 pre-test (device_math.h any_decide's reject half) would have kept out
-				const f2 mm = (-b) - rp.two_a, m2 = mm * mm * 0x1.00004p+0f;
-				const bool k0 = cand0 && ((mm.x <= 0.0f) || (m2.x < D.x)), k1 = cand1 && ((mm.y <= 0.0f) || (m2.y < D.y));
-				const unsigned long long c0 = __ballot(cand0), c1 = __ballot(cand1), a0 = __ballot(acc0), a1 = __ballot(acc1), r0 = __ballot(k0), r1 = __ballot(k1);
-				DIAG_WAVE(13, __popcll(c0) + __popcll(c1));                 // candidate rays
-				DIAG_WAVE(14, __popcll(a0) + __popcll(a1));                 // accepted
-				DIAG_WAVE(17, __popcll(r0) + __popcll(r1));                 // certainly t2 <= 1
-				DIAG_WAVE(18, ((c0 & ~r0) | (c1 & ~r1)) ? 1 : 0);           // paths still taken with the pre-test
-			}
-#endif
 			best_update(s0, acc0, i, l0, h0, b.x, D.x);
 			best_update(s1, acc1, i, l1, h1, b.y, D.y);
 		}
-	}
+	};
+	sphere_rows(sv, test);
 	best_resolve(sv, o, d0, rp.four_a.x, s0);
 	if(second) best_resolve(sv, o, d1, rp.four_a.y, s1);
 }
@@ -205,7 +190,7 @@ SKR_DEV SceneView stage_scene(const RenderParams &p, float4 *lds4, bool tris)
 	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
 	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	__syncthreads();
-	return SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, tris ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work, SKR_GEOM_SMEM ? p.sph_geom : s_geom};
+	return SceneView{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, tris ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work, p.sph_geom};
 }
 
 SKR_DEV void add_counters(const RenderParams &p, const Counters &cn, uint32_t shard, int lane)
