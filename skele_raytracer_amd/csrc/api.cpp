@@ -44,6 +44,7 @@ struct skr_renderer {
 	skr_scene_info info{};
 	float4 *d_blob = nullptr; // one allocation: geom | amb | kd | ks | lights | tris | chunk trees | triangle materials
 	size_t blob_bytes = 0;
+	float4 *d_camec = nullptr; // per sphere {cam_pos - centre, |.|^2 - r^2} (render_wave.hip skr_camec_kernel), + 16 rows of padding
 	bool is_clone = false;    // skr_renderer_clone: the scene blob and the work counters belong to the renderer it was cloned from
 	size_t off_amb = 0, off_kd = 0, off_ks = 0, off_lights = 0, off_tris = 0, off_chunks = 0, off_tri_mats = 0;
 	int n_chunks = 0, chunk_size = 0, cones = 0;
@@ -83,6 +84,8 @@ static void load_switches(SkrSwitches &sw)
 	if(const char *e = getenv("SKR_LEVELS_BUDGET_MB")) sw.budget_mb = atoi(e) > 0 ? atoi(e) : 1;
 	if(const char *e = getenv("SKR_FLAT")) sw.flat = atoi(e) > 0 ? 1 : -1;
 }
+
+hipError_t skr_launch_camec(const float4 *geom, int ns, f3 cam_pos, float4 *out, hipStream_t stream); // render_wave.hip
 
 // (multi_gpu.cpp) a clone follows its source's development switches: tests change them between frames
 void skr_copy_switches(skr_renderer *dst, const skr_renderer *src) { dst->sw = src->sw; }
@@ -166,9 +169,18 @@ int skr_renderer_create(const skr_scene *scene, int device, skr_renderer **out)
 	if(e == hipSuccess) e = hipMemset(r->d_counters, 0, (SKR_COUNTER_SHARDS * 4 + 16) * sizeof(unsigned long long) + (SKR_PULL_QUEUES + 2 + 2 * SKR_P1_REGIONS) * SKR_PULL_STRIDE * sizeof(uint32_t));
 	if(e == hipSuccess) e = hipMalloc((void **) &r->d_tri_work, 256 * 2 * sizeof(unsigned long long));
 	if(e == hipSuccess) e = hipMemset(r->d_tri_work, 0, 256 * 2 * sizeof(unsigned long long));
+	if(e == hipSuccess) e = hipMalloc((void **) &r->d_camec, (ns + 16) * 16);
+	if(e == hipSuccess) e = hipMemset(r->d_camec, 0, (ns + 16) * 16);
+	if(e == hipSuccess)
+	{ // the camera belongs to the scene: its (e, c) rows are formed once, on the device, by the operations every ray would perform
+		const float *c = scene->info.camera;
+		e = skr_launch_camec(r->d_blob, (int) ns, f3{c[0], c[1], c[2]}, r->d_camec, nullptr);
+		if(e == hipSuccess) e = hipDeviceSynchronize();
+	}
 	if(e != hipSuccess)
 	{
 		skr_set_error("scene upload failed: %s", hipGetErrorString(e));
+		if(r->d_camec) (void) hipFree(r->d_camec);
 		if(r->d_blob) (void) hipFree(r->d_blob);
 		if(r->d_counters) (void) hipFree(r->d_counters);
 		if(r->d_tri_work) (void) hipFree(r->d_tri_work);
@@ -197,6 +209,7 @@ int skr_renderer_clone(const skr_renderer *src, skr_renderer **out)
 	r->info = src->info;
 	r->d_blob = src->d_blob;
 	r->blob_bytes = src->blob_bytes;
+	r->d_camec = src->d_camec;
 	r->is_clone = true;
 	r->off_amb = src->off_amb; r->off_kd = src->off_kd; r->off_ks = src->off_ks; r->off_lights = src->off_lights;
 	r->off_tris = src->off_tris; r->off_chunks = src->off_chunks; r->off_tri_mats = src->off_tri_mats;
@@ -215,6 +228,7 @@ void skr_renderer_destroy(skr_renderer *r)
 	if(!r) return;
 	(void) hipSetDevice(r->device);
 	if(r->d_blob && !r->is_clone) (void) hipFree(r->d_blob);
+	if(r->d_camec && !r->is_clone) (void) hipFree(r->d_camec);
 	if(r->d_counters && !r->is_clone) (void) hipFree(r->d_counters);
 	if(r->d_tri_work && !r->is_clone) (void) hipFree(r->d_tri_work);
 	if(r->d_snap) (void) hipFree(r->d_snap);
@@ -311,6 +325,7 @@ static int render_pass(skr_renderer *r, const skr_options *opt, uint32_t tile_ro
 	p.n_tris = r->info.n_triangles;
 	p.n_lights = r->info.n_point_lights + r->info.n_directional_lights; // (directional ones only under --strict-scn)
 	p.sph_geom = r->d_blob;
+	p.cam_ec = r->d_camec;
 	p.sph_amb = r->d_blob + r->off_amb;
 	p.sph_kd = r->d_blob + r->off_kd;
 	p.sph_ks = r->d_blob + r->off_ks;

@@ -42,6 +42,7 @@ struct RenderParams {
 	// SoA scene in HBM (scene_host.h)
 	int32_t n_spheres, n_tris, n_lights;
 	const float4 *sph_geom, *sph_amb, *sph_kd, *sph_ks, *lights, *tris;
+	const float4 *cam_ec;     // per sphere {cam_pos - centre, |cam_pos - centre|^2 - r^2}: e and c of utils.h:115-118 for every ray that starts at the camera (skr_camec_kernel)
 	const float4 *tri_chunks; // the chunk tree of the triangle walk (scene_host.h): 3 float4 per node, depth-first, skip links, then 2 float4 per chunk
 	int32_t tri_chunk_size;
 	int32_t tri_cones;        // some entry has a tight radius for non-grazing rays (else the cone test is compiled out of the walk)

@@ -18,7 +18,7 @@
 #include "wave_common.h"
 
 // One workgroup = 4 independent waves; wave w of block (bx, by) owns the 8x8 pixel tile (2*bx + (w&1), 2*by + (w>>1)).
-// Dynamic LDS: scene SoA (shared, staged once) | the camera's (e, c) per sphere | per wave 192 bytes of packed RGB.  TRIS = false: no triangles in the scene,
+// Dynamic LDS: scene SoA (shared, staged once) | per wave 192 bytes of packed RGB.  TRIS = false: no triangles in the scene,
 // the walk is compiled out.
 template <bool TRIS>
 __global__ __launch_bounds__(256) void skr_direct_kernel(const RenderParams p)
@@ -27,21 +27,7 @@ __global__ __launch_bounds__(256) void skr_direct_kernel(const RenderParams p)
 	float4 *lds4 = reinterpret_cast<float4 *>(lds_raw);
 	const SceneView sv = stage_scene(p, lds4, TRIS); // the only workgroup barrier
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-	// every primary ray starts at the camera: e = o - C, c = e.e - r^2 per sphere, once per workgroup (closest_sphere_from)
-	float4 *s_camec = lds4 + 4 * p.n_spheres + 1 + 2 * p.n_lights; // ns + 1 rows
-	for(int i = tid; i <= p.n_spheres; i += 256)
-	{
-		float4 row = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-		if(i < p.n_spheres)
-		{
-			const float4 g = sv.geom[i];
-			const f3 e = p.cam_pos - ld3(g);
-			row = make_float4(e.x, e.y, e.z, dot3(e, e) - g.w);
-		}
-		s_camec[i] = row;
-	}
-	__syncthreads();
-	unsigned char *s_tile = reinterpret_cast<unsigned char *>(s_camec + p.n_spheres + 1) + wave * 192;
+	unsigned char *s_tile = reinterpret_cast<unsigned char *>(lds4 + 4 * p.n_spheres + 1 + 2 * p.n_lights) + wave * 192;
 	const int lx = lane & 7, ly = lane >> 3;
 	const int x0 = (blockIdx.x * 2 + (wave & 1)) * 8;
 	const uint32_t orow0 = (blockIdx.y * 2 + (wave >> 1)) * 8u;
@@ -65,7 +51,7 @@ __global__ __launch_bounds__(256) void skr_direct_kernel(const RenderParams p)
 			cn.rays++;
 			const RayConst r = make_ray(p.cam_pos, dir);
 			float tmin;
-			const int sph = closest_sphere_from(sv, s_camec, r, tmin);                // raytrace.h:152-165
+			const int sph = closest_sphere_from(sv, p.cam_ec, r, tmin);               // raytrace.h:152-165 (every primary ray starts at the camera)
 			if(sv.nt > 0 && any_triangle_closer(sv, r, tmin)) smp = mk3(0, 0, 0);     // :171-186, :221-224
 			else if(sph < 0) smp = p.background;                                      // :189-192
 			else
@@ -151,19 +137,6 @@ __global__ __launch_bounds__(256) SKR_PRIMARY_ATTR void skr_primary_kernel(const
 	}
 	for(int i = tid; i < 2 * nl; i += 256) s_lights[i] = p.lights[i];
 	if(tid == 0) s_geom[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	// the camera's (e, c) per sphere for closest_sphere_from (as in skr_direct_kernel), behind the counts
-	float4 *s_camec = lds4 + 4 * ns + 1 + 2 * nl + 2; // ns + 1 rows
-	for(int i = tid; i <= ns; i += 256)
-	{
-		float4 row = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-		if(i < ns)
-		{
-			const float4 g = p.sph_geom[i];
-			const f3 e = p.cam_pos - ld3(g);
-			row = make_float4(e.x, e.y, e.z, dot3(e, e) - g.w);
-		}
-		s_camec[i] = row;
-	}
 	__syncthreads();
 	const SceneView sv{s_geom, s_amb, s_kd, s_ks, s_lights, p.tris, ns, TRIS ? p.n_tris : 0, nl, p.tri_chunks, p.n_tri_chunks, p.tri_chunk_size, p.tri_cones, p.tri_work, p.sph_geom};
 
@@ -190,7 +163,7 @@ __global__ __launch_bounds__(256) SKR_PRIMARY_ATTR void skr_primary_kernel(const
 		cn.rays++;
 		const RayConst r = make_ray(p.cam_pos, dir);
 		float tmin;
-		const int sph = closest_sphere_from(sv, s_camec, r, tmin);
+		const int sph = closest_sphere_from(sv, p.cam_ec, r, tmin);
 		if(sv.nt > 0 && any_triangle_closer(sv, r, tmin)) colour = mk3(0, 0, 0);
 		else if(sph < 0) colour = p.background;
 		else
@@ -242,6 +215,21 @@ __global__ __launch_bounds__(256) SKR_PRIMARY_ATTR void skr_primary_kernel(const
 	}
 }
 
+// Once per renderer: e = cam_pos - C and c = e.e - r^2 of utils.h:115-118 per sphere, for every ray that starts at the camera (closest_sphere_from).
+__global__ void skr_camec_kernel(const float4 *geom, int ns, f3 cam_pos, float4 *out)
+{
+	const int i = (int) (blockIdx.x * blockDim.x + threadIdx.x);
+	if(i >= ns) return;
+	const float4 g = geom[i];
+	const f3 e = cam_pos - ld3(g);
+	out[i] = make_float4(e.x, e.y, e.z, dot3(e, e) - g.w);
+}
+hipError_t skr_launch_camec(const float4 *geom, int ns, f3 cam_pos, float4 *out, hipStream_t stream)
+{
+	if(ns > 0) hipLaunchKernelGGL(skr_camec_kernel, dim3((unsigned) (ns + 255) / 256), dim3(256), 0, stream, geom, ns, cam_pos, out);
+	return hipGetLastError();
+}
+
 // AA only: image[y][x] /= g*g (main.cpp:165), then the quantiser (main.cpp:205).
 __global__ __launch_bounds__(256) void skr_resolve_kernel(const RenderParams p)
 {
@@ -272,7 +260,7 @@ __global__ __launch_bounds__(256) void skr_resolve_kernel(const RenderParams p)
 // test.scn (1800 triangles, 4 spheres) 0.556 / 0.485 ms at 3 / 4.
 size_t skr_wave_lds_bytes(const RenderParams &p)
 {
-	const size_t need = ((size_t) 5 * p.n_spheres + 2 + 2 * p.n_lights) * 16 + 4 * 192; // scene | camera (e, c) rows | tile bytes
+	const size_t need = ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 4 * 192; // scene | tile bytes
 	const size_t third = 53248; // 3 x 53 248 B are co-resident on a CU (1280-byte granules), 4 are not
 	return (p.n_tris > 0 && p.n_spheres == 0 && need < third) ? third : need;
 }
@@ -295,7 +283,6 @@ hipError_t skr_launch_wave(const RenderParams &p, hipStream_t stream)
 // ---- launch wrappers for the node pipeline (render_nodes.hip)
 hipError_t skr_launch_primary(const RenderParams &p, dim3 grid, size_t lds, hipStream_t stream)
 {
-	lds += ((size_t) p.n_spheres + 1) * 16; // (the scene + 32 bytes of counts the caller sized, and the camera's (e, c) rows)
 	if(p.n_tris > 0) hipLaunchKernelGGL(skr_primary_kernel<true>, grid, dim3(256), lds, stream, p);
 	else hipLaunchKernelGGL(skr_primary_kernel<false>, grid, dim3(256), lds, stream, p);
 	return hipGetLastError();

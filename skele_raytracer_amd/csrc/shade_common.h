@@ -48,16 +48,15 @@ SKR_DEV float4 load_const4(const float4 *base, int i)
 #ifndef SKR_SPHERE_TRIP
 #define SKR_SPHERE_TRIP 4
 #endif
-template <typename F>
-SKR_DEV void sphere_rows(const SceneView &sv, F test)
+template <int K, typename F, typename G>
+SKR_DEV void table_rows(const float4 *base, int n, F test, G go_on)
 {
-	constexpr int K = SKR_SPHERE_TRIP;
-	auto row = [&](int i) { return load_const4(sv.geom_u, i); }; // (up to 2 K - 1 rows behind the spheres are asked for and never used: the scene blob is padded for them, api.cpp)
+	auto row = [&](int i) { return load_const4(base, i); }; // (up to 2 K - 1 rows behind the table are asked for and never used: the tables are padded for them, api.cpp)
 	float4 nx[K];
 #pragma unroll
 	for(int k = 0; k < K; k++) nx[k] = row(k);
 	int i = 0;
-	for(; i + K <= sv.ns; i += K)
+	for(; i + K <= n; i += K)
 	{
 		float4 g[K];
 #pragma unroll
@@ -69,10 +68,16 @@ SKR_DEV void sphere_rows(const SceneView &sv, F test)
 		__builtin_amdgcn_sched_barrier(0); // the next trip's rows are asked for here, a whole trip ahead of their use
 #pragma unroll
 		for(int k = 0; k < K; k++) test(g[k], i + k);
+		if(!go_on()) return;
 	}
 #pragma unroll
 	for(int k = 0; k < K - 1; k++)
-		if(i + k < sv.ns) test(nx[k], i + k);
+		if(i + k < n) test(nx[k], i + k);
+}
+template <typename F>
+SKR_DEV void sphere_rows(const SceneView &sv, F test)
+{
+	table_rows<SKR_SPHERE_TRIP>(sv.geom_u, sv.ns, test, [] { return true; });
 }
 
 // Row i of the mesh tables (triangles, culling data: HBM, never written by a kernel), i wave-uniform: one s_load_dwordx4 into SGPRs.
@@ -188,19 +193,20 @@ SKR_DEV int closest_sphere(const SceneView &sv, const RayConst &r, float &tmin)
 }
 
 // closest_sphere() for rays that all start at ONE point (the camera: main.cpp:140-182), with e = o - C and c = e.e - r^2 of utils.h:115-118
-// formed once per sphere for the whole workgroup (ec[i] = {e.xyz, c}: the same subtractions, products and sums in the same order, so the same
-// floats) instead of once per ray: 9 of the ~17 instructions a sphere costs a ray.
+// formed once per sphere and renderer (ec[i] = {e.xyz, c}: the same subtractions, products and sums in the same order, on the device, so the
+// same floats: skr_camec_kernel, render_wave.hip) instead of once per ray: 9 of the ~17 instructions a sphere costs a ray.  The rows are
+// read like the sphere rows of the level pipelines: scalar loads, several per trip (table_rows).
+#ifndef SKR_CAMERA_TRIP
+#define SKR_CAMERA_TRIP 4 // spheres per trip of closest_sphere_from: config 2 (15 spheres) 1.312 / 1.284 / 1.19 ms at 1 / 2 / 4 (with the shadow loop at the same count), bear.scn (31) 0.518 / 0.500 / 0.451
+#endif
 SKR_DEV int closest_sphere_from(const SceneView &sv, const float4 *ec, const RayConst &r, float &tmin)
 {
 	const RayFilt f = make_filt(r.d);
 	int best = -1;
 	float best_lo = __builtin_inff(), best_hi = __builtin_inff(), others_lo = __builtin_inff();
 	float best_b = 0.0f, best_D = 0.0f;
-	float4 q_next = ec[0];
-	for(int i = 0; i < sv.ns; i++)
+	table_rows<SKR_CAMERA_TRIP>(ec, sv.ns, [&](const float4 q, int i)
 	{
-		const float4 q = q_next;
-		q_next = ec[i + 1]; // (one pad entry, like geom[])
 		float lo, hi, b, D;
 		if(bracket_from_ec(ld3(q), q.w, r.d, f, lo, hi, b, D))
 		{
@@ -215,7 +221,7 @@ SKR_DEV int closest_sphere_from(const SceneView &sv, const float4 *ec, const Ray
 			}
 			else others_lo = __builtin_fminf(others_lo, lo);
 		}
-	}
+	}, [] { return true; });
 	tmin = __builtin_inff();
 	if(best >= 0)
 	{
@@ -341,6 +347,9 @@ SKR_DEV bool any_triangle_closer(const SceneView &sv, const RayConst &r, float t
 // and the loop is left once every lane's rays are occluded.  The level pipelines' lanes are hits from all over the scene: the wave-wide
 // test never fires there and costs a branch and half a dozen instructions per sphere (headline leaf kernel 1.282 -> 1.247 ms without
 // it; two spheres per trip written out by hand, on top: 1.287 ms — eight more live registers, 47 spilled instead of 24).
+#ifndef SKR_COHERENT_TRIP
+#define SKR_COHERENT_TRIP 4 // spheres per trip of the coherent shadow loop (the wave-wide exit is looked at once per trip)
+#endif
 template <bool COHERENT>
 SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second, bool &occ0, bool &occ1, uint32_t &tests)
 {
@@ -377,18 +386,7 @@ SKR_DEV void occluded_pair(const SceneView &sv, f3 P, f3 L0, f3 L1, bool second,
 			}
 		}
 	};
-	if(COHERENT)
-	{
-		float4 g_next = sv.geom[0];
-		for(int i = 0; i < sv.ns; i++)
-		{
-			const float4 g = g_next;
-			g_next = sv.geom[i + 1];
-			__builtin_amdgcn_sched_barrier(0); // the prefetch is issued here, a whole trip ahead of its use, not behind the arithmetic
-			test(g, i);
-			if(__all(occ0 && occ1)) break;
-		}
-	}
+	if(COHERENT) table_rows<SKR_COHERENT_TRIP>(sv.geom_u, sv.ns, test, [&] { return !__all(occ0 && occ1); }); // (the wave-wide exit, once per trip)
 	else sphere_rows(sv, test);
 	if(!occ0) tests += (uint32_t) sv.ns;
 	if(second && !occ1) tests += (uint32_t) sv.ns;
