@@ -163,11 +163,8 @@ SKR_DEV int closest_sphere(const SceneView &sv, const RayConst &r, float &tmin)
 	int best = -1;
 	float best_lo = __builtin_inff(), best_hi = __builtin_inff(), others_lo = __builtin_inff();
 	float best_b = 0.0f, best_D = 0.0f;
-	float4 g_next = sv.geom[0];
-	for(int i = 0; i < sv.ns; i++)
+	sphere_rows(sv, [&](const float4 g, int i)
 	{
-		const float4 g = g_next;
-		g_next = sv.geom[i + 1];
 		float lo, hi, b, D;
 		if(sphere_bracket(r.o, r.d, f, g, lo, hi, b, D))
 		{
@@ -182,7 +179,7 @@ SKR_DEV int closest_sphere(const SceneView &sv, const RayConst &r, float &tmin)
 			}
 			else others_lo = __builtin_fminf(others_lo, lo);
 		}
-	}
+	});
 	tmin = __builtin_inff();
 	if(best >= 0)
 	{
