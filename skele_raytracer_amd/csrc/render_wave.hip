@@ -19,8 +19,9 @@
 
 // One workgroup = 4 independent waves; wave w of block (bx, by) owns the 8x8 pixel tile (2*bx + (w&1), 2*by + (w>>1)).
 // Dynamic LDS: scene SoA (shared, staged once) | per wave 192 bytes of packed RGB.  TRIS = false: no triangles in the scene,
-// the walk is compiled out.
-template <bool TRIS>
+// the walk is compiled out; SPH = false: no spheres, the sphere test and all the shading are (a frame that is all mesh is all walk, and
+// the walk's scalar registers are what its speed hangs on: with the sphere code compiled in beside it dragon.scn takes 1.27 instead of 1.2 ms).
+template <bool TRIS, bool SPH>
 __global__ __launch_bounds__(256) void skr_direct_kernel(const RenderParams p)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -50,10 +51,11 @@ __global__ __launch_bounds__(256) void skr_direct_kernel(const RenderParams p)
 			primary_ray(p, x, y, pixel, (uint32_t) s, dir);
 			cn.rays++;
 			const RayConst r = make_ray(p.cam_pos, dir);
-			float tmin;
-			const int sph = closest_sphere_from(sv, p.cam_ec, r, tmin);               // raytrace.h:152-165 (every primary ray starts at the camera)
+			float tmin = __builtin_inff();
+			int sph = -1;
+			if(SPH) sph = closest_sphere_from(sv, p.cam_ec, r, tmin);                 // raytrace.h:152-165 (every primary ray starts at the camera)
 			if(sv.nt > 0 && any_triangle_closer(sv, r, tmin)) smp = mk3(0, 0, 0);     // :171-186, :221-224
-			else if(sph < 0) smp = p.background;                                      // :189-192
+			else if(!SPH || sph < 0) smp = p.background;                              // :189-192
 			else
 			{
 				cn.hits++;
@@ -261,7 +263,10 @@ __global__ __launch_bounds__(256) void skr_resolve_kernel(const RenderParams p)
 size_t skr_wave_lds_bytes(const RenderParams &p)
 {
 	const size_t need = ((size_t) 4 * p.n_spheres + 1 + 2 * p.n_lights) * 16 + 4 * 192; // scene | tile bytes
-	const size_t third = 53248; // 3 x 53 248 B are co-resident on a CU (1280-byte granules), 4 are not
+#ifndef SKR_MESH_LDS_PAD
+#define SKR_MESH_LDS_PAD 53248 // 3 x 53 248 B are co-resident on a CU (1280-byte granules), 4 are not
+#endif
+	const size_t third = SKR_MESH_LDS_PAD;
 	return (p.n_tris > 0 && p.n_spheres == 0 && need < third) ? third : need;
 }
 
@@ -272,11 +277,15 @@ hipError_t skr_launch_wave(const RenderParams &p, hipStream_t stream)
 {
 	const dim3 grid((p.width + 15) / 16, (p.out_rows + 15) / 16);
 	const size_t lds = skr_wave_lds_bytes(p);
-	const void *fn = p.n_tris > 0 ? reinterpret_cast<const void *>(skr_direct_kernel<true>) : reinterpret_cast<const void *>(skr_direct_kernel<false>);
+	const bool tris = p.n_tris > 0, sph = p.n_spheres > 0;
+	const void *fn = tris ? (sph ? reinterpret_cast<const void *>(skr_direct_kernel<true, true>) : reinterpret_cast<const void *>(skr_direct_kernel<true, false>))
+	                      : (sph ? reinterpret_cast<const void *>(skr_direct_kernel<false, true>) : reinterpret_cast<const void *>(skr_direct_kernel<false, false>));
 	hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); // > 64 KiB of dynamic LDS per workgroup has to be opted into
 	if(e != hipSuccess) return e;
-	if(p.n_tris > 0) hipLaunchKernelGGL(skr_direct_kernel<true>, grid, dim3(256), lds, stream, p);
-	else hipLaunchKernelGGL(skr_direct_kernel<false>, grid, dim3(256), lds, stream, p);
+	if(tris && sph) hipLaunchKernelGGL((skr_direct_kernel<true, true>), grid, dim3(256), lds, stream, p);
+	else if(tris) hipLaunchKernelGGL((skr_direct_kernel<true, false>), grid, dim3(256), lds, stream, p);
+	else if(sph) hipLaunchKernelGGL((skr_direct_kernel<false, true>), grid, dim3(256), lds, stream, p);
+	else hipLaunchKernelGGL((skr_direct_kernel<false, false>), grid, dim3(256), lds, stream, p);
 	return hipGetLastError();
 }
 
