@@ -293,6 +293,34 @@ def test_synthetic_scenes_match_oracle(gpu, oracle, tmp_path, n_spheres, n_light
     assert cnt["radiance_rays"] == int(st[0]) and cnt["sphere_hits"] == int(st[1])
 
 
+@pytest.mark.parametrize("n_spheres", [1, 2, 3, 4, 5, 7, 8, 9, 12, 13, 16, 17])
+def test_sphere_counts_around_the_trip_size(gpu, oracle, tmp_path, monkeypatch, n_spheres):
+    """The sphere loops take the sphere rows four per trip through the scalar cache and ask for the rows of the next trip without a
+    bounds test (shade_common.h table_rows: the tables are padded): every count around the trip size, through the direct kernel, both
+    schedules of the node pipeline, the general level pipeline and --legacy-reflect, against the oracle bit for bit, counts included."""
+    rng = np.random.default_rng(500 + n_spheres)
+    scn = str(tmp_path / "count.scn")
+    _write_synthetic_scn(scn, rng, n_spheres, 2, 0)
+    w, h = 64, 36
+    r = skr.Renderer(skr.parse_scene(scn))
+    for kw, env in ((dict(shadow=True, jsample=2, seed=1), {}),
+                    (dict(gillum=4, shadow=True, seed=2), {"SKR_FLAT": "0"}),
+                    (dict(gillum=4, shadow=True, seed=2), {"SKR_FLAT": "1"}),
+                    (dict(gillum=3, depth=4, shadow=True, seed=3), {"SKR_PIPELINE": "generic"}),
+                    (dict(depth=3, shadow=True, legacy_reflect=True), {})):
+        for k in ("SKR_FLAT", "SKR_PIPELINE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r.counters(reset=True)
+        rgb, rgbf = r.render(skr.Options(w, h, **kw), want_float=True)
+        gpu.cuda.synchronize()
+        cnt = r.counters(reset=True)
+        o_rgb, o_f, st = oracle.render(scn, w, h, rng=oracle.RNG_COUNTER, math=oracle.MATH_SHARED, want_float=True, **kw)
+        compare(rgb.cpu().numpy(), rgbf.cpu().numpy(), o_rgb, o_f, "%d spheres %s %s [%s]" % (n_spheres, kw, env, r.kernel_variant()))
+        assert (cnt["radiance_rays"], cnt["sphere_hits"], cnt["shadow_rays"]) == tuple(int(v) for v in st[:3]), (n_spheres, kw, env)
+
+
 def test_full_size_config5_rows_against_oracle(gpu, oracle):
     """BASELINE config 5 at its real size (3840x2160 --gillum 64 --jsample 5 --shadow, ~9e10 radiance rays):
     whole frame on the GPU (25 AA samples through the parent-queue pipeline), two row bands bit for bit
